@@ -1,0 +1,23 @@
+// The context object behind h2v_ctx (include/h2v.h).
+#pragma once
+#include "internal.h"
+#include "pairing_api.h"
+#include <mutex>
+
+namespace h2v { struct VkDevice; }
+
+struct h2v_ctx {
+    int device = 0;
+    h2v::ParamsHost params;
+    h2v::PairingDevice pairing;
+    h2v::MsmWorkspace msm_ws;      // used by h2v_msm_g1 only; batches own their workspaces
+    hipStream_t stream = nullptr;  // used by the synchronous single-shot entry points
+    std::mutex mu;                 // serialises the single-shot entry points
+    h2v::VkDevice* vk = nullptr;   // per-VK compiled program and constants (vkplan.hip)
+};
+
+namespace h2v {
+int ctx_load_vk(h2v_ctx* ctx, const uint8_t* vk, size_t vk_len, int vk_format);
+void ctx_release_vk(h2v_ctx* ctx);
+int affine_to_jacobian_enqueue(hipStream_t s, const G1A* d_in, G1J* d_out, uint32_t n);
+}  // namespace h2v

@@ -1,0 +1,132 @@
+// BN254 G1 group law for gfx950 kernels (and the host side of the library).
+// y^2 = x^3 + 3 over Fq; Jacobian coordinates (X/Z^2, Y/Z^3), identity <=> Z == 0.
+// Affine points are stored as (x, y) in Montgomery form; (0, 0) is not on the curve and marks
+// the identity.
+//
+// Replaces the halo2curves G1 arithmetic the reference reaches through
+// MSMKZG::eval -> best_multiexp (poly/kzg/msm.rs:81-86, arithmetic.rs:7-108) and through
+// G1Affine::from_bytes (transcript/mod.rs:158-166).
+#pragma once
+#include "bn254.cuh"
+
+namespace h2v {
+
+// compressed-point flag bits (SURVEY.md §8c "Unpinned detail"): byte 31 bit 7 = identity, bit 6 = sign(y)
+static constexpr uint8_t G1_FLAG_IDENTITY = 0x80;
+static constexpr uint8_t G1_FLAG_SIGN = 0x40;
+
+struct G1A {
+    Fq x, y;
+    H2V_HD bool is_identity() const { return x.is_zero() && y.is_zero(); }
+    H2V_HD static G1A identity() { G1A p; p.x = Fq::zero(); p.y = Fq::zero(); return p; }
+    H2V_HD bool on_curve() const {
+        if (is_identity()) return true;
+        Fq three = Fq::from_u32(3);
+        return y.sqr() == x.sqr() * x + three;
+    }
+};
+
+struct G1J {
+    Fq X, Y, Z;
+    H2V_HD static G1J identity() { G1J p; p.X = Fq::zero(); p.Y = Fq::one(); p.Z = Fq::zero(); return p; }
+    H2V_HD bool is_identity() const { return Z.is_zero(); }
+    H2V_HD static G1J from_affine(const G1A& a) {
+        if (a.is_identity()) return identity();
+        G1J p; p.X = a.x; p.Y = a.y; p.Z = Fq::one(); return p;
+    }
+    H2V_HD G1J neg() const { G1J r = *this; r.Y = Y.neg(); return r; }
+};
+
+H2V_FN G1J g1_dbl(const G1J& p) {
+    if (p.is_identity()) return p;
+    Fq A = p.X.sqr(), B = p.Y.sqr(), C = B.sqr();
+    Fq D = ((p.X + B).sqr() - A - C).dbl();
+    Fq E = A.dbl() + A, F = E.sqr();
+    G1J r;
+    r.X = F - D.dbl();
+    r.Y = E * (D - r.X) - C.dbl().dbl().dbl();
+    r.Z = (p.Y * p.Z).dbl();
+    return r;
+}
+
+H2V_FN G1J g1_add(const G1J& p, const G1J& q) {
+    if (p.is_identity()) return q;
+    if (q.is_identity()) return p;
+    Fq Z1Z1 = p.Z.sqr(), Z2Z2 = q.Z.sqr();
+    Fq U1 = p.X * Z2Z2, U2 = q.X * Z1Z1;
+    Fq S1 = p.Y * q.Z * Z2Z2, S2 = q.Y * p.Z * Z1Z1;
+    if (U1 == U2) {
+        if (S1 == S2) return g1_dbl(p);
+        return G1J::identity();
+    }
+    Fq H = U2 - U1, I = H.dbl().sqr(), J = H * I, rr = (S2 - S1).dbl(), V = U1 * I;
+    G1J r;
+    r.X = rr.sqr() - J - V.dbl();
+    r.Y = rr * (V - r.X) - (S1 * J).dbl();
+    r.Z = ((p.Z + q.Z).sqr() - Z1Z1 - Z2Z2) * H;
+    return r;
+}
+
+H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) {
+    if (q.is_identity()) return p;
+    if (p.is_identity()) return G1J::from_affine(q);
+    Fq Z1Z1 = p.Z.sqr();
+    Fq U2 = q.x * Z1Z1, S2 = q.y * p.Z * Z1Z1;
+    if (p.X == U2) {
+        if (p.Y == S2) return g1_dbl(p);
+        return G1J::identity();
+    }
+    Fq H = U2 - p.X, HH = H.sqr(), I = HH.dbl().dbl(), J = H * I, rr = (S2 - p.Y).dbl(), V = p.X * I;
+    G1J r;
+    r.X = rr.sqr() - J - V.dbl();
+    r.Y = rr * (V - r.X) - (p.Y * J).dbl();
+    r.Z = (p.Z + H).sqr() - Z1Z1 - HH;
+    return r;
+}
+
+H2V_FN G1A g1_to_affine(const G1J& p) {
+    if (p.is_identity()) return G1A::identity();
+    Fq zi = p.Z.inv(), zi2 = zi.sqr();
+    G1A a; a.x = p.X * zi2; a.y = p.Y * zi2 * zi;
+    return a;
+}
+
+// k * P for a small unsigned k (wave-uniform or per-lane; used in the window reduction)
+H2V_FN G1J g1_mul_u32(const G1J& p, uint32_t k) {
+    G1J r = G1J::identity();
+    for (int i = 31; i >= 0; --i) {
+        r = g1_dbl(r);
+        if ((k >> i) & 1) r = g1_add(r, p);
+    }
+    return r;
+}
+
+// sqrt in Fq for p = 3 mod 4: a^((p+1)/4); caller checks r^2 == a
+H2V_FN Fq fq_sqrt_candidate(const Fq& a) {
+    // (p+1)/4 = 0x0c19139cb84c680a6e14116da060561765e05aa45a1c72a34f082305b61f3f52
+    const uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+    return a.pow_limbs(e);
+}
+
+// G1Affine::from_bytes (compressed).  Returns false for an invalid encoding.
+H2V_FN bool g1_decompress(const uint8_t in[32], G1A& out) {
+    uint8_t tmp[32];
+    for (int i = 0; i < 32; ++i) tmp[i] = in[i];
+    bool is_inf = tmp[31] & G1_FLAG_IDENTITY, sign = tmp[31] & G1_FLAG_SIGN;
+    tmp[31] &= 0x3f;
+    Fq x;
+    if (!Fq::from_bytes(tmp, x)) return false;
+    if (is_inf) {
+        if (!x.is_zero() || sign) return false;
+        out = G1A::identity();
+        return true;
+    }
+    Fq rhs = x.sqr() * x + Fq::from_u32(3);
+    Fq y = fq_sqrt_candidate(rhs);
+    if (y.sqr() != rhs) return false;
+    if (y.is_odd() != sign) y = y.neg();
+    out.x = x; out.y = y;
+    return true;
+}
+
+}  // namespace h2v

@@ -1,0 +1,57 @@
+// Internal declarations shared by the translation units of libh2v_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "curve.cuh"
+
+namespace h2v {
+
+void set_last_error(const std::string& s);
+#define H2V_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            ::h2v::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));           \
+            return H2V_ERR_DEVICE;                                                              \
+        }                                                                                       \
+    } while (0)
+
+// ------------------------------------------------------------------ MSM (msm.hip)
+// Pippenger over pooled (scalar, base) terms.  Scalars: canonical little-endian limbs, 8 x u32 per
+// term; bases: affine Montgomery, (0,0) = identity (skipped).
+struct MsmPlan {
+    uint32_t n;        // terms
+    uint32_t c;        // window bits
+    uint32_t windows;  // ceil(254 / c)
+    uint32_t buckets;  // 2^c - 1 per window
+};
+MsmPlan msm_plan(uint32_t n);
+
+struct MsmWorkspace {
+    uint32_t cap_terms = 0;
+    uint32_t* counts = nullptr;   // [windows * buckets]
+    uint32_t* offsets = nullptr;  // [windows * buckets]
+    uint32_t* cursor = nullptr;   // [windows * buckets]
+    uint32_t* list = nullptr;     // [cap_terms * max_windows]
+    G1J* bucket_pts = nullptr;    // [windows * buckets]
+    G1J* window_sums = nullptr;   // [max_windows]
+    size_t cap_buckets = 0, cap_list = 0;
+    int alloc(uint32_t max_terms);
+    void release();
+};
+// Enqueue sum_i scalars[i] * bases[i] -> *out (Jacobian, device memory).  Asynchronous on `s`.
+int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, const G1A* d_bases, uint32_t n, G1J* d_out);
+
+// ------------------------------------------------------------------ small helpers (util.hip)
+// canonical x|y bytes (64 B each, all-zero = identity) -> affine Montgomery; flags[i] = 0 ok, 1 not canonical / not on curve
+int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, uint32_t* d_flags, uint32_t n);
+// canonical 32-B scalars -> 8 x u32 limbs (validated < r); flags[i] = 1 when >= r
+int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
+// Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
+int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n);
+// acc[0] = sum of parts[2*i], acc[1] = sum of parts[2*i+1]
+int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc2);
+
+}  // namespace h2v

@@ -1,0 +1,155 @@
+/* h2v.h — C ABI of the MI355X-native Halo2/KZG/SHPLONK batch verifier.
+ *
+ * The reference (ChainSafe/halo2-verifier, pure Rust, no FFI of its own) exposes the hot path
+ * through Rust traits; this header is what an `extern "C"` block on the Rust side binds
+ * (INTEGRATION.md shows the shim).  Each entry point cites the reference item it replaces;
+ * paths are relative to the reference repository root.
+ *
+ * Conventions
+ *   - All buffers are caller-owned; the library never retains a host pointer past the call
+ *     that received it.  No exceptions or panics cross the boundary.
+ *   - Return value 0 = OK; negative = error.  -1..-6 mirror plonk::Error
+ *     (halo2_verifier/src/plonk/mod.rs:19-32) in declaration order.
+ *   - Field elements: 32 bytes little-endian canonical (== ff::PrimeField::to_repr).
+ *   - G1 points at this boundary: x | y, 64 bytes canonical, all-zero = identity.
+ *   - Proofs, VerifyingKey and ParamsKZG bytes are in the reference's own formats
+ *     (VerifyingKey::write  halo2_verifier/src/plonk/vk.rs:41-64;
+ *      ParamsKZG::write_custom  halo2_verifier/src/poly/kzg/commitment.rs:142-152).
+ *   - serde format codes follow helpers.rs:7-19: 0 Processed, 1 RawBytes, 2 RawBytesUnchecked.
+ *   - Threading: a context is immutable after creation and may be shared between host
+ *     threads; a batch object owns one HIP stream and its device workspace and must be used
+ *     from one thread at a time.  Several batches may be in flight on one context.
+ */
+#ifndef H2V_H
+#define H2V_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2V_OK 0
+#define H2V_ERR_INVALID_INSTANCES (-1)         /* Error::InvalidInstances          lib.rs:51-55          */
+#define H2V_ERR_CONSTRAINT_SYSTEM_FAILURE (-2) /* Error::ConstraintSystemFailure   kzg/strategy.rs:171-175 */
+#define H2V_ERR_BOUNDS_FAILURE (-3)            /* Error::BoundsFailure                                     */
+#define H2V_ERR_OPENING (-4)                   /* Error::Opening                   lib.rs:420-424        */
+#define H2V_ERR_TRANSCRIPT (-5)                /* Error::Transcript                plonk/mod.rs:34-39    */
+#define H2V_ERR_INSTANCE_TOO_LARGE (-6)        /* Error::InstanceTooLarge                                  */
+#define H2V_ERR_REFERENCE_PANIC (-7)  /* inputs on which the reference panics: zero inverse (vanishing.rs:100, shplonk.rs:215) */
+#define H2V_ERR_BAD_ARGUMENT (-16)
+#define H2V_ERR_FORMAT (-17)          /* VK / params bytes rejected (io::Error in VerifyingKey::read / ParamsKZG::read_custom) */
+#define H2V_ERR_DEVICE (-18)          /* HIP runtime error; h2v_last_error() has the text */
+#define H2V_ERR_UNSUPPORTED (-19)
+
+#define H2V_SERDE_PROCESSED 0
+#define H2V_SERDE_RAW_BYTES 1
+#define H2V_SERDE_RAW_BYTES_UNCHECKED 2
+
+typedef struct h2v_ctx h2v_ctx;
+typedef struct h2v_batch h2v_batch;
+
+/* Library / device probe: number of HIP devices visible (0 if none; never fails). */
+int h2v_device_count(void);
+/* Text of the most recent error on this thread (never NULL). */
+const char* h2v_last_error(void);
+
+/* Context = ParamsKZG + VerifyingKey resident on one GPU, plus everything derived from them
+ * once per VK (evaluation domain constants, the compiled per-proof program, G2 line
+ * coefficients).
+ *   replaces: ParamsKZG::read_custom (poly/kzg/commitment.rs:155-207),
+ *             VerifyingKey::read (plonk/vk.rs:76-115) -> EvaluationDomain::new (poly/domain.rs:34-140),
+ *             G2Prepared::from (poly/kzg/msm.rs:186-187).
+ * vk may be NULL (vk_len 0) for a context that only serves h2v_msm_g1 / h2v_pairing_check. */
+int h2v_ctx_create(const uint8_t* params, size_t params_len, int params_format,
+                   const uint8_t* vk, size_t vk_len, int vk_format,
+                   int device, h2v_ctx** out);
+void h2v_ctx_destroy(h2v_ctx* ctx);
+
+/* Shape of one proof for this VK (Np points, Ns scalars, T_R right-channel terms). */
+int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points, size_t* n_scalars,
+                        size_t* n_right_terms, size_t* n_instance_columns);
+
+/* sum_i scalars[i] * bases[i] in G1.
+ *   replaces: MSMKZG::eval + to_affine (poly/kzg/msm.rs:81-86) == best_multiexp (arithmetic.rs:102-108). */
+int h2v_msm_g1(h2v_ctx* ctx, const uint8_t* scalars32, const uint8_t* bases64, size_t n,
+               uint8_t out_xy[64], int* out_is_identity);
+
+/* e(left, s_g2) * e(right, -g2) == 1 ?
+ *   replaces: DualMSM::check after both channels are evaluated (poly/kzg/msm.rs:185-203). */
+int h2v_pairing_check(h2v_ctx* ctx, const uint8_t left_xy[64], const uint8_t right_xy[64], int* ok);
+
+/* N x verify_proof under AccumulatorStrategy, then finalize():
+ *   replaces: the loop  s = verify_proof(&params, &vk, s, instances_i, &mut Blake2bRead::init(proof_i))?
+ *             followed by s.finalize()   (lib.rs:33-425, poly/kzg/strategy.rs:125-140).
+ * proofs[i] / proof_lens[i]: proof byte strings.  Instances: one circuit instance per proof
+ * (instances.len() == 1 in the reference's terms); instances32[i] is the concatenation of that
+ * proof's instance columns, col_lens[c] the number of values in column c (same for every proof
+ * of the batch), n_instance_columns must equal the VK's (else H2V_ERR_INVALID_INSTANCES).
+ * rand32: the n scalars that AccumulatorStrategy::process draws with Fr::random
+ * (kzg/strategy.rs:129), in call order; NULL = draw from the OS RNG.
+ * per_proof_status[i]: 0 or the plonk::Error the reference's verify_proof returns for proof i;
+ * a failing proof contributes nothing to the accumulator.
+ * batch_ok: all statuses OK and the single pairing check passed.
+ * out_left_xy / out_right_xy: the two evaluated channels of the final DualMSM (may be NULL). */
+int h2v_verify_batch(h2v_ctx* ctx, size_t n,
+                     const uint8_t* const* proofs, const size_t* proof_lens,
+                     const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens,
+                     const uint8_t* rand32,
+                     int* per_proof_status, int* batch_ok,
+                     uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
+
+/* N x verify_proof under SingleStrategy (one pairing per proof; poly/kzg/strategy.rs:164-176).
+ * per_proof_status[i] = 0, or H2V_ERR_CONSTRAINT_SYSTEM_FAILURE when that proof's pairing fails,
+ * or the transcript/opening error. */
+int h2v_verify_each(h2v_ctx* ctx, size_t n,
+                    const uint8_t* const* proofs, const size_t* proof_lens,
+                    const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens,
+                    int* per_proof_status);
+
+/* Debug / parity: the Guard of one proof in reference term order (shplonk.rs:256-264), and the
+ * Fiat-Shamir challenges [user challenges.., theta, beta, gamma, y, x, y', v, u].
+ * On entry *n_right / *n_left / *n_challenges hold the capacities (in elements). */
+int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len,
+                  const uint8_t* instances32, size_t n_instance_columns, const size_t* col_lens,
+                  uint8_t* right_scalars32, uint8_t* right_bases64, size_t* n_right,
+                  uint8_t* left_scalars32, uint8_t* left_bases64, size_t* n_left,
+                  uint8_t* challenges32, size_t* n_challenges);
+
+/* ---- staged interface: inputs resident in HBM, asynchronous execution on the batch's stream.
+ * h2v_verify_batch == upload + launch + finish.  A sharded (multi-GPU) run uses
+ * h2v_batch_launch_accumulate on every rank, exchanges the 2 accumulator points, and calls
+ * h2v_fold_check once. */
+int h2v_batch_create(h2v_ctx* ctx, size_t max_proofs, size_t max_instance_values_per_proof, h2v_batch** out);
+void h2v_batch_destroy(h2v_batch* b);
+/* Host -> device copy of one shard.  proofs_flat = n * proof_len bytes, instances_flat = n * (sum col_lens) * 32 bytes.
+ * rand32_tail: the Fr::random draws of proofs [first_index, total) of the whole (possibly sharded)
+ * batch — the multiplier of proof i is the product of the draws of all later proofs
+ * (kzg/strategy.rs:129, msm.rs:173-176) — n_tail = total - first_index >= n. NULL = OS RNG (unsharded only). */
+int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len,
+                     const uint8_t* instances_flat, size_t n_instance_columns, const size_t* col_lens,
+                     const uint8_t* rand32_tail, size_t n_tail);
+/* Enqueue decompress -> transcript -> Fr program -> fold -> MSM (-> pairing if with_pairing). */
+int h2v_batch_launch(h2v_batch* b, int with_pairing);
+/* Wait for the stream and fetch results (any pointer may be NULL). */
+int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
+/* Device address of this batch's two accumulator points after launch: 2 x 96 bytes, Jacobian
+ * (X, Y, Z) in the library's Montgomery limb layout — opaque bytes to be moved by a collective. */
+int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes);
+/* The HIP stream (hipStream_t) the batch runs on, for event timing and stream-ordered interop. */
+void* h2v_batch_stream(h2v_batch* b);
+/* Fold n_parts accumulator pairs (as produced by h2v_batch_accumulators, contiguous in device
+ * memory) with G1 additions and run the single pairing check.
+ *   replaces: DualMSM::add_msm + check across shards (poly/kzg/msm.rs:178-203). */
+int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts, int* ok,
+                   uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
+/* Per-stage device time of the last finished launch, milliseconds, measured with HIP events on
+ * the batch's stream: [decompress, transcript, fr_program, fold, msm, pairing]; returns count. */
+int h2v_batch_timings(h2v_batch* b, float* ms, int cap);
+int h2v_batch_set_profiling(h2v_batch* b, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2V_H */
