@@ -1,0 +1,67 @@
+// The batch object behind h2v_batch and the argument blocks of the per-proof kernels.
+#pragma once
+#include "ctx.h"
+#include "vkplan.h"
+
+namespace h2v {
+
+struct FrvmArgs {
+    const VmInstr* code; uint32_t n_code;
+    const Fr* consts;
+    Fr* slots;
+    uint32_t n;
+    const uint8_t* proofs; uint32_t proof_len; const uint32_t* scalar_offsets;
+    const uint8_t* inst; uint32_t ninst;
+    const Fr* chal; const Fr* mult;
+    int* status;
+    uint32_t* msm_scal; uint32_t np;
+    Fr* shared;
+    uint32_t* left_scal;
+};
+
+struct StageArgs {
+    uint32_t n;
+    const Plan* plan; const PlanDevice* pd;
+    const uint8_t* proofs; const uint8_t* inst;
+    G1A* pts; uint8_t* ycanon; int* status;
+    unsigned long long* words; uint32_t stream_words;
+    Fr* chal;
+};
+
+int decompress_stage_enqueue(hipStream_t s, const StageArgs& g);
+int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
+int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, Fr* d_mult);
+int frvm_enqueue(hipStream_t s, const FrvmArgs& a);
+int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t* d_msm_scal);
+int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared,
+                       uint32_t slot_h2, G1J* d_pairs);
+// strided MSM (msm.hip): term i reads scalars[i * scalar_stride_words ..+8) and bases[i * base_stride]
+int msm_enqueue_strided(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, uint32_t scalar_stride_words, const G1A* d_bases, uint32_t base_stride,
+                        uint32_t n, G1J* d_out);
+
+}  // namespace h2v
+
+struct h2v_batch {
+    h2v_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    size_t max_proofs = 0, max_inst = 0;
+    h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
+    uint32_t n = 0, n_tail = 0;
+    bool launched = false, with_pairing = false, single = false;
+    // device buffers (sized for max_proofs with the plan of the first upload; re-allocated if a later plan needs more)
+    uint8_t* proofs = nullptr; uint8_t* inst = nullptr; uint8_t* tail = nullptr;
+    h2v::G1A* pts = nullptr; uint8_t* ycanon = nullptr; int* status = nullptr;
+    unsigned long long* words = nullptr; h2v::Fr* chal = nullptr; h2v::Fr* mult = nullptr; h2v::Fr* slots = nullptr;
+    uint32_t* msm_scal = nullptr; h2v::Fr* shared = nullptr; uint32_t* left_scal = nullptr;
+    h2v::G1J* acc = nullptr;      // [0] left, [1] right
+    h2v::G1J* pairs = nullptr;    // per-proof channels (SingleStrategy)
+    uint32_t* ok = nullptr;       // [max_proofs] (index 0 for the batch check)
+    uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
+    h2v::MsmWorkspace ws_right, ws_left;
+    size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
+    uint32_t stream_words = 0;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[8] = {nullptr};
+    float last_ms[6] = {0, 0, 0, 0, 0, 0};
+};

@@ -1,0 +1,385 @@
+// C-ABI batch verification entry points (include/h2v.h): staged upload / launch / finish, the
+// one-shot h2v_verify_batch / h2v_verify_each / h2v_guard_msm built on them, and h2v_fold_check.
+#include "../../include/h2v.h"
+#include "batch.h"
+#include <string.h>
+#include <stdio.h>
+
+using namespace h2v;
+
+namespace {
+
+template <class T> int dev_alloc(T*& p, size_t count) {
+    if (p) { hipFree(p); p = nullptr; }
+    H2V_HIP_CHECK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    return 0;
+}
+
+// (re)allocate the per-batch device workspace for a given plan
+int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
+    const Plan& pl = pd->host;
+    size_t N = b->max_proofs;
+    size_t sig = (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
+    if (b->cap_plan_sig == sig && b->pts) return 0;
+    int rc;
+    uint32_t words = (uint32_t)((pl.stream.size() + 7) / 8);
+    words = (words + 15) / 16 * 16;  // whole 128-byte blocks
+    b->stream_words = words;
+    if ((rc = dev_alloc(b->proofs, N * pl.proof_len))) return rc;
+    if ((rc = dev_alloc(b->inst, N * (size_t)pl.n_instance_values * 32))) return rc;
+    if ((rc = dev_alloc(b->pts, N * pl.n_points + pl.n_shared))) return rc;
+    if ((rc = dev_alloc(b->ycanon, N * pl.n_points * 32))) return rc;
+    if ((rc = dev_alloc(b->status, N))) return rc;
+    if ((rc = dev_alloc(b->words, (size_t)words * N))) return rc;
+    if ((rc = dev_alloc(b->chal, (size_t)pl.squeeze_at.size() * N))) return rc;
+    if ((rc = dev_alloc(b->mult, N))) return rc;
+    if ((rc = dev_alloc(b->slots, (size_t)pl.n_slots * N))) return rc;
+    if ((rc = dev_alloc(b->msm_scal, (N * pl.n_points + pl.n_shared) * 8))) return rc;
+    if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
+    if ((rc = dev_alloc(b->left_scal, N * 8))) return rc;
+    if ((rc = dev_alloc(b->acc, 2))) return rc;
+    if ((rc = dev_alloc(b->pairs, 2 * N))) return rc;
+    if ((rc = dev_alloc(b->ok, N))) return rc;
+    if ((rc = dev_alloc(b->out_bytes, 128))) return rc;
+    if ((rc = dev_alloc(b->out_ident, 2))) return rc;
+    if ((rc = b->ws_right.alloc((uint32_t)(N * pl.n_points + pl.n_shared)))) return rc;
+    if ((rc = b->ws_left.alloc((uint32_t)N))) return rc;
+    b->cap_plan_sig = sig;
+    return 0;
+}
+
+bool scalar_is_canonical(const uint8_t* s) {
+    uint32_t raw[8];
+    for (int j = 0; j < 8; ++j) raw[j] = (uint32_t)s[4 * j] | ((uint32_t)s[4 * j + 1] << 8) | ((uint32_t)s[4 * j + 2] << 16) | ((uint32_t)s[4 * j + 3] << 24);
+    return !Fr::geq_p(raw);
+}
+
+// Fr::random(getrandom_or_panic()) of AccumulatorStrategy::process (kzg/strategy.rs:129): 64 OS-random bytes reduced mod r
+int os_random_scalars(std::vector<uint8_t>& out, size_t n) {
+    out.resize(32 * n);
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f) { set_last_error("cannot open /dev/urandom"); return H2V_ERR_DEVICE; }
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t buf[64];
+        if (fread(buf, 1, 64, f) != 64) { fclose(f); set_last_error("short read from /dev/urandom"); return H2V_ERR_DEVICE; }
+        uint32_t w[16];
+        for (int j = 0; j < 16; ++j) w[j] = (uint32_t)buf[4 * j] | ((uint32_t)buf[4 * j + 1] << 8) | ((uint32_t)buf[4 * j + 2] << 16) | ((uint32_t)buf[4 * j + 3] << 24);
+        Fr::from_uniform_words(w).to_bytes(&out[32 * i]);
+    }
+    fclose(f);
+    return 0;
+}
+
+int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len, const uint8_t* instances_flat, size_t ncols, const size_t* col_lens,
+                const uint8_t* rand_tail, size_t n_tail) {
+    if (!b || (n && !proofs_flat)) { set_last_error("h2v_batch_upload: null argument"); return H2V_ERR_BAD_ARGUMENT; }
+    if (n > b->max_proofs) { set_last_error("h2v_batch_upload: n exceeds the batch capacity"); return H2V_ERR_BAD_ARGUMENT; }
+    h2v_ctx* ctx = b->ctx;
+    if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
+    if (ncols != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }  // lib.rs:51-55
+    std::vector<size_t> lens(col_lens, col_lens + ncols);
+    PlanDevice* pd = nullptr;
+    int rc = ctx_get_plan(ctx, lens, &pd);
+    if (rc) return rc;
+    const Plan& pl = pd->host;
+    if (proof_len < pl.proof_len) { set_last_error("h2v_batch_upload: proof_len is shorter than this VK's proof"); return H2V_ERR_BAD_ARGUMENT; }
+    if (pl.n_instance_values && n && !instances_flat) { set_last_error("h2v_batch_upload: instances missing"); return H2V_ERR_BAD_ARGUMENT; }
+    if (rand_tail && n_tail < n) { set_last_error("h2v_batch_upload: n_tail < n"); return H2V_ERR_BAD_ARGUMENT; }
+    H2V_HIP_CHECK(hipSetDevice(ctx->device));
+    if ((rc = ensure_buffers(b, pd))) return rc;
+    b->plan = pd; b->n = (uint32_t)n; b->launched = false;
+    std::vector<uint8_t> os_rand;
+    if (!rand_tail) { if ((rc = os_random_scalars(os_rand, n))) return rc; rand_tail = os_rand.data(); n_tail = n; }
+    for (size_t i = 0; i < n_tail; ++i) if (!scalar_is_canonical(rand_tail + 32 * i)) { set_last_error("h2v_batch_upload: rand32 scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; }
+    if (n_tail > b->cap_tail) { if ((rc = dev_alloc(b->tail, 32 * n_tail))) return rc; b->cap_tail = n_tail; }
+    b->n_tail = (uint32_t)n_tail;
+    hipStream_t s = b->stream;
+    if (n) {
+        if (proof_len == pl.proof_len) H2V_HIP_CHECK(hipMemcpyAsync(b->proofs, proofs_flat, n * proof_len, hipMemcpyHostToDevice, s));
+        else H2V_HIP_CHECK(hipMemcpy2DAsync(b->proofs, pl.proof_len, proofs_flat, proof_len, pl.proof_len, n, hipMemcpyHostToDevice, s));
+        if (pl.n_instance_values) H2V_HIP_CHECK(hipMemcpyAsync(b->inst, instances_flat, n * (size_t)pl.n_instance_values * 32, hipMemcpyHostToDevice, s));
+        H2V_HIP_CHECK(hipMemcpyAsync(b->tail, rand_tail, 32 * n_tail, hipMemcpyHostToDevice, s));
+        // VK-wide bases sit behind the batch's own points so that one MSM covers both
+        H2V_HIP_CHECK(hipMemcpyAsync(b->pts + n * (size_t)pl.n_points, pd->shared_bases, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, s));
+    }
+    H2V_HIP_CHECK(hipStreamSynchronize(s));  // the host buffers are the caller's again
+    return 0;
+}
+
+int launch_impl(h2v_batch* b, int with_pairing, bool single) {
+    if (!b || !b->plan) { set_last_error("h2v_batch_launch: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
+    h2v_ctx* ctx = b->ctx;
+    H2V_HIP_CHECK(hipSetDevice(ctx->device));
+    PlanDevice* pd = b->plan;
+    const Plan& pl = pd->host;
+    hipStream_t s = b->stream;
+    uint32_t n = b->n;
+    b->with_pairing = with_pairing != 0; b->single = single; b->launched = true;
+    int rc;
+    int ev = 0;
+    auto mark = [&]() { if (b->profiling) hipEventRecord(b->ev[ev], s); ++ev; };
+    mark();
+    StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->ycanon, b->status, b->words, b->stream_words, b->chal};
+    // stage 1: point decompression + canonicity checks; stage 2: absorbed stream, Blake2b challenges, batch multipliers
+    if ((rc = decompress_stage_enqueue(s, g))) return rc;
+    mark();
+    if ((rc = transcript_stage_enqueue(s, g))) return rc;
+    if (n) { if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, b->mult))) return rc; }
+    mark();
+    FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
+               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal};
+    if ((rc = frvm_enqueue(s, a))) return rc;
+    mark();
+    if (single) {
+        if ((rc = single_msm_enqueue(s, b->msm_scal, b->shared, b->pts, n, pl.n_points, pl.n_shared, pl.slot_h2, b->pairs))) return rc;
+        mark(); mark();
+        if ((rc = pairing_check_enqueue(s, ctx->pairing, b->pairs, n, b->ok))) return rc;
+        mark();
+        return 0;
+    }
+    if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, b->msm_scal))) return rc; }
+    mark();
+    uint32_t terms = n ? n * pl.n_points + pl.n_shared : 0;
+    if ((rc = msm_enqueue_strided(s, b->ws_right, b->msm_scal, 8, b->pts, 1, terms, b->acc + 1))) return rc;
+    if ((rc = msm_enqueue_strided(s, b->ws_left, b->left_scal, 8, b->pts + pl.slot_h2, pl.n_points, n, b->acc + 0))) return rc;
+    mark();
+    if (with_pairing) { if ((rc = pairing_check_enqueue(s, ctx->pairing, b->acc, 1, b->ok))) return rc; }
+    mark();
+    if ((rc = point_to_bytes_enqueue(s, b->acc, b->out_bytes, b->out_ident, 2))) return rc;
+    return 0;
+}
+
+int finish_impl(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t* out_left, uint8_t* out_right) {
+    if (!b || !b->launched) { set_last_error("h2v_batch_finish: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
+    H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
+    hipStream_t s = b->stream;
+    uint32_t n = b->n;
+    std::vector<int> st(n ? n : 1, 0);
+    std::vector<uint32_t> okv(b->single ? (n ? n : 1) : 1, 1);
+    uint8_t outb[128]; memset(outb, 0, 128);
+    if (n) H2V_HIP_CHECK(hipMemcpyAsync(st.data(), b->status, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    if (b->single) { if (n) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * n, hipMemcpyDeviceToHost, s)); }
+    else {
+        if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4, hipMemcpyDeviceToHost, s));
+        H2V_HIP_CHECK(hipMemcpyAsync(outb, b->out_bytes, 128, hipMemcpyDeviceToHost, s));
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_last_error(std::string("h2v_batch_finish: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
+    if (b->profiling) {
+        // events: 0 start, 1 after decompression, 2 after transcript + multipliers, 3 after Fr program, 4 after fold, 5 after MSMs, 6 after pairing
+        float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t45 = 0, t56 = 0;
+        hipEventElapsedTime(&t01, b->ev[0], b->ev[1]); hipEventElapsedTime(&t12, b->ev[1], b->ev[2]); hipEventElapsedTime(&t23, b->ev[2], b->ev[3]);
+        hipEventElapsedTime(&t34, b->ev[3], b->ev[4]); hipEventElapsedTime(&t45, b->ev[4], b->ev[5]); hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
+        b->last_ms[0] = t01; b->last_ms[1] = t12; b->last_ms[2] = t23; b->last_ms[3] = t34; b->last_ms[4] = t45; b->last_ms[5] = t56;
+    }
+    bool all_ok = true;
+    for (uint32_t i = 0; i < n; ++i) {
+        int v = st[i];
+        if (b->single && v == 0 && !okv[i]) v = H2V_ERR_CONSTRAINT_SYSTEM_FAILURE;  // kzg/strategy.rs:171-175
+        if (per_proof_status) per_proof_status[i] = v;
+        if (v != 0) all_ok = false;
+    }
+    if (batch_ok) *batch_ok = b->single ? (all_ok ? 1 : 0) : ((all_ok && (!b->with_pairing || okv[0])) ? 1 : 0);
+    if (out_left) memcpy(out_left, outb, 64);
+    if (out_right) memcpy(out_right, outb + 64, 64);
+    return 0;
+}
+
+// pack pointer-array proofs / instances into the flat layout; proofs shorter than the VK's proof are
+// the reader running dry: "failed to fill whole buffer" -> Error::Transcript, or Opening inside the multi-open part
+int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t ncols,
+                 const size_t* col_lens, const uint8_t* rand32, bool single, int with_pairing, int* per_proof_status, int* batch_ok, uint8_t* out_left,
+                 uint8_t* out_right, h2v_batch** keep) {
+    if (!ctx || (n && (!proofs || !proof_lens)) || (ncols && !col_lens)) { set_last_error("null argument"); return H2V_ERR_BAD_ARGUMENT; }
+    if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
+    if (ncols != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
+    std::vector<size_t> lens(col_lens, col_lens + ncols);
+    PlanDevice* pd = nullptr;
+    int rc = ctx_get_plan(ctx, lens, &pd);
+    if (rc) return rc;
+    const Plan& pl = pd->host;
+    size_t per_inst = (size_t)pl.n_instance_values * 32;
+    std::vector<uint8_t> flat(n * pl.proof_len, 0), iflat(n * per_inst, 0);
+    std::vector<int> forced(n, 0);
+    // byte offset where the multi-open part starts: h1 is the first point after all scalars
+    size_t opening_at = pl.point_offsets[pl.slot_h1];
+    for (size_t i = 0; i < n; ++i) {
+        if (!proofs[i]) { set_last_error("null proof pointer"); return H2V_ERR_BAD_ARGUMENT; }
+        if (proof_lens[i] < pl.proof_len) {
+            // the reader runs dry; every point of the packed copy is made undecodable (x = 2^254-1 >= p) so that the proof
+            // contributes nothing, and the status is set to what the reference reports for the place where it ran dry
+            forced[i] = proof_lens[i] < opening_at ? H2V_ERR_TRANSCRIPT : H2V_ERR_OPENING;
+            memset(&flat[i * pl.proof_len], 0xff, pl.proof_len);
+        } else memcpy(&flat[i * pl.proof_len], proofs[i], pl.proof_len);
+        if (per_inst) { if (!instances32 || !instances32[i]) { set_last_error("null instances pointer"); return H2V_ERR_BAD_ARGUMENT; } memcpy(&iflat[i * per_inst], instances32[i], per_inst); }
+    }
+    h2v_batch* b = nullptr;
+    if ((rc = h2v_batch_create(ctx, n ? n : 1, pl.n_instance_values, &b))) return rc;
+    do {
+        std::vector<uint8_t> ones;
+        const uint8_t* tail = rand32;
+        if (single) { ones.assign(32 * (n ? n : 1), 0); for (size_t i = 0; i < n; ++i) ones[32 * i] = 1; tail = ones.data(); }
+        if ((rc = upload_impl(b, n, flat.data(), pl.proof_len, iflat.data(), ncols, col_lens, tail, tail ? n : 0))) break;
+        if ((rc = launch_impl(b, with_pairing, single))) break;
+        std::vector<int> st(n ? n : 1, 0);
+        int ok = 0;
+        if ((rc = finish_impl(b, st.data(), &ok, out_left, out_right))) break;
+        for (size_t i = 0; i < n; ++i) if (forced[i]) { st[i] = forced[i]; ok = 0; }
+        if (per_proof_status) for (size_t i = 0; i < n; ++i) per_proof_status[i] = st[i];
+        if (batch_ok) *batch_ok = ok;
+    } while (0);
+    if (keep && !rc) *keep = b; else h2v_batch_destroy(b);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points, size_t* n_scalars, size_t* n_right_terms, size_t* n_instance_columns) {
+    if (!ctx || !ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
+    // the layout does not depend on instance lengths; compile (or fetch) the plan for empty columns of the right count
+    std::vector<size_t> lens(ctx->vk->vk.num_instance_columns, 0);
+    PlanDevice* pd = nullptr;
+    int rc = ctx_get_plan(const_cast<h2v_ctx*>(ctx), lens, &pd);
+    if (rc) return rc;
+    if (proof_len) *proof_len = pd->host.proof_len;
+    if (n_points) *n_points = pd->host.n_points;
+    if (n_scalars) *n_scalars = pd->host.n_scalars;
+    if (n_right_terms) *n_right_terms = pd->host.right_term_order.size();
+    if (n_instance_columns) *n_instance_columns = ctx->vk->vk.num_instance_columns;
+    return 0;
+}
+
+int h2v_batch_create(h2v_ctx* ctx, size_t max_proofs, size_t max_instance_values_per_proof, h2v_batch** out) {
+    if (!ctx || !out || !max_proofs) { set_last_error("h2v_batch_create: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
+    if (max_proofs > (1u << 22)) { set_last_error("h2v_batch_create: max_proofs too large"); return H2V_ERR_BAD_ARGUMENT; }
+    H2V_HIP_CHECK(hipSetDevice(ctx->device));
+    h2v_batch* b = new h2v_batch();
+    b->ctx = ctx; b->max_proofs = max_proofs; b->max_inst = max_instance_values_per_proof;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { delete b; set_last_error("hipStreamCreate failed"); return H2V_ERR_DEVICE; }
+    for (int i = 0; i < 8; ++i) hipEventCreate(&b->ev[i]);
+    *out = b;
+    return 0;
+}
+
+void h2v_batch_destroy(h2v_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
+    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->acc); hipFree(b->pairs); hipFree(b->ok);
+    hipFree(b->out_bytes); hipFree(b->out_ident);
+    b->ws_right.release(); b->ws_left.release();
+    for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len, const uint8_t* instances_flat, size_t n_instance_columns,
+                     const size_t* col_lens, const uint8_t* rand32_tail, size_t n_tail) {
+    return upload_impl(b, n, proofs_flat, proof_len, instances_flat, n_instance_columns, col_lens, rand32_tail, n_tail);
+}
+int h2v_batch_launch(h2v_batch* b, int with_pairing) { return launch_impl(b, with_pairing, false); }
+int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    return finish_impl(b, per_proof_status, batch_ok, out_left_xy, out_right_xy);
+}
+int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes) {
+    if (!b || !b->acc || !device_ptr) { set_last_error("h2v_batch_accumulators: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
+    *device_ptr = b->acc;
+    if (nbytes) *nbytes = 2 * sizeof(G1J);
+    return 0;
+}
+void* h2v_batch_stream(h2v_batch* b) { return b ? (void*)b->stream : nullptr; }
+int h2v_batch_set_profiling(h2v_batch* b, int enabled) { if (!b) return H2V_ERR_BAD_ARGUMENT; b->profiling = enabled != 0; return 0; }
+int h2v_batch_timings(h2v_batch* b, float* ms, int cap) {
+    if (!b || !ms) return H2V_ERR_BAD_ARGUMENT;
+    int k = cap < 6 ? cap : 6;
+    for (int i = 0; i < k; ++i) ms[i] = b->last_ms[i];
+    return k;
+}
+
+int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts, int* ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    if (!ctx || !device_accumulators || !n_parts || !ok) { set_last_error("h2v_fold_check: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    H2V_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    G1J* acc = nullptr; uint32_t* d_ok = nullptr; uint8_t* d_out = nullptr; uint32_t* d_ident = nullptr;
+    H2V_HIP_CHECK(hipMalloc(&acc, 2 * sizeof(G1J))); H2V_HIP_CHECK(hipMalloc(&d_ok, 4)); H2V_HIP_CHECK(hipMalloc(&d_out, 128)); H2V_HIP_CHECK(hipMalloc(&d_ident, 8));
+    int rc = 0; uint32_t okv = 0; uint8_t outb[128];
+    do {
+        if ((rc = fold_pairs_enqueue(s, (const G1J*)device_accumulators, (uint32_t)n_parts, acc))) break;
+        if ((rc = pairing_check_enqueue(s, ctx->pairing, acc, 1, d_ok))) break;
+        if ((rc = point_to_bytes_enqueue(s, acc, d_out, d_ident, 2))) break;
+        if (hipMemcpyAsync(&okv, d_ok, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(outb, d_out, 128, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_last_error(std::string("h2v_fold_check: ") + hipGetErrorString(e)); rc = H2V_ERR_DEVICE; break; }
+        *ok = (int)okv;
+        if (out_left_xy) memcpy(out_left_xy, outb, 64);
+        if (out_right_xy) memcpy(out_right_xy, outb + 64, 64);
+    } while (0);
+    hipFree(acc); hipFree(d_ok); hipFree(d_out); hipFree(d_ident);
+    return rc;
+}
+
+int h2v_verify_batch(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,
+                     const size_t* col_lens, const uint8_t* rand32, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    return pack_and_run(ctx, n, proofs, proof_lens, instances32, n_instance_columns, col_lens, rand32, false, 1, per_proof_status, batch_ok, out_left_xy, out_right_xy, nullptr);
+}
+
+int h2v_verify_each(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,
+                    const size_t* col_lens, int* per_proof_status) {
+    int ok = 0;
+    return pack_and_run(ctx, n, proofs, proof_lens, instances32, n_instance_columns, col_lens, nullptr, true, 1, per_proof_status, &ok, nullptr, nullptr, nullptr);
+}
+
+int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len, const uint8_t* instances32, size_t n_instance_columns, const size_t* col_lens,
+                  uint8_t* right_scalars32, uint8_t* right_bases64, size_t* n_right, uint8_t* left_scalars32, uint8_t* left_bases64, size_t* n_left,
+                  uint8_t* challenges32, size_t* n_challenges) {
+    if (!ctx || !proof || !n_right || !n_left) { set_last_error("h2v_guard_msm: null argument"); return H2V_ERR_BAD_ARGUMENT; }
+    uint8_t one[32] = {1};
+    const uint8_t* pp[1] = {proof}; size_t pl1[1] = {proof_len}; const uint8_t* ip[1] = {instances32};
+    int st = 0, ok = 0;
+    h2v_batch* b = nullptr;
+    int rc = pack_and_run(ctx, 1, pp, pl1, ip, n_instance_columns, col_lens, one, false, 0, &st, &ok, nullptr, nullptr, &b);
+    if (rc) return rc;
+    if (st != 0) { h2v_batch_destroy(b); return st; }
+    const Plan& pl = b->plan->host;
+    size_t T = pl.right_term_order.size();
+    do {
+        if (T > *n_right || 1 > *n_left) { set_last_error("h2v_guard_msm: output capacity too small"); rc = H2V_ERR_BAD_ARGUMENT; break; }
+        std::vector<uint32_t> scal((size_t)pl.n_points * 8);
+        std::vector<Fr> shared(pl.n_shared);
+        std::vector<G1A> pts(pl.n_points + pl.n_shared);
+        std::vector<Fr> chal(pl.squeeze_at.size());
+        if (hipMemcpy(scal.data(), b->msm_scal, scal.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(shared.data(), b->shared, sizeof(Fr) * pl.n_shared, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(pts.data(), b->pts, sizeof(G1A) * pts.size(), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(chal.data(), b->chal, sizeof(Fr) * chal.size(), hipMemcpyDeviceToHost) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
+        auto put_pt = [](const G1A& p, uint8_t* o) { if (p.is_identity()) memset(o, 0, 64); else { p.x.to_bytes(o); p.y.to_bytes(o + 32); } };
+        for (size_t t = 0; t < T; ++t) {
+            auto w = pl.right_term_order[t];
+            if (w.first) { shared[w.second].to_bytes(right_scalars32 + 32 * t); put_pt(pts[pl.n_points + w.second], right_bases64 + 64 * t); }
+            else { memcpy(right_scalars32 + 32 * t, &scal[(size_t)w.second * 8], 32); put_pt(pts[w.second], right_bases64 + 64 * t); }
+        }
+        *n_right = T;
+        memset(left_scalars32, 0, 32); left_scalars32[0] = 1;
+        put_pt(pts[pl.slot_h2], left_bases64);
+        *n_left = 1;
+        if (challenges32 && n_challenges) {
+            // reorder squeeze order -> [user challenges.., theta, beta, gamma, y, x, y', v, u]
+            size_t nc = pl.n_challenges;
+            if (nc > *n_challenges) { set_last_error("h2v_guard_msm: challenge capacity too small"); rc = H2V_ERR_BAD_ARGUMENT; break; }
+            // squeeze order is the transcript order; user challenges are interleaved by phase. Rebuild the map as compile_plan did.
+            const VkHost& vk = ctx->vk->vk;
+            std::vector<uint32_t> order;
+            uint8_t max_phase = 0; for (uint8_t p2 : vk.advice_column_phase) max_phase = std::max(max_phase, p2);
+            for (unsigned ph = 0; ph <= max_phase; ++ph) for (uint32_t i = 0; i < vk.num_challenges; ++i) if (vk.challenge_phase[i] == ph) order.push_back(i);
+            for (uint32_t i = 0; i < 8; ++i) order.push_back(vk.num_challenges + i);
+            for (size_t q = 0; q < order.size() && q < chal.size(); ++q) chal[q].to_bytes(challenges32 + 32 * order[q]);
+            *n_challenges = nc;
+        }
+    } while (0);
+    h2v_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"

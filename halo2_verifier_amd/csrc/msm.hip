@@ -21,7 +21,7 @@
 // O(10^4-10^5) integer ops per 96 bytes: the kernel is bound by 32-bit integer multiply issue,
 // not by HBM (DESIGN.md "Roofline").
 #include "../../include/h2v.h"
-#include "internal.h"
+#include "batch.h"
 
 namespace h2v {
 
@@ -82,14 +82,14 @@ __device__ __forceinline__ uint32_t msm_digit(const uint32_t* __restrict__ s, ui
 }
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) msm_count_or_scatter(const uint32_t* __restrict__ scalars, const G1A* __restrict__ bases, uint32_t n, MsmPlan p,
+__global__ void __launch_bounds__(256) msm_count_or_scatter(const uint32_t* __restrict__ scalars, uint32_t sstride, const G1A* __restrict__ bases, uint32_t bstride, uint32_t n, MsmPlan p,
                                                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const uint32_t* s = scalars + 8 * (size_t)t;  // digits are read straight from L1/L2: no runtime-indexed register array
+    const uint32_t* s = scalars + (size_t)sstride * t;  // digits are read straight from L1/L2: no runtime-indexed register array
     // identity bases contribute nothing
-    const uint32_t* bw = reinterpret_cast<const uint32_t*>(bases + t);
+    const uint32_t* bw = reinterpret_cast<const uint32_t*>(bases + (size_t)bstride * t);
     uint32_t any = 0;
     for (int i = 0; i < 16; ++i) any |= bw[i];
     if (!any) return;
@@ -126,14 +126,14 @@ __global__ void __launch_bounds__(1024) msm_scan(const uint32_t* __restrict__ co
     for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; cursor[i] = 0; }
 }
 
-__global__ void __launch_bounds__(64) msm_bucket(const G1A* __restrict__ bases, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(64) msm_bucket(const G1A* __restrict__ bases, uint32_t bstride, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                  const uint32_t* __restrict__ list, G1J* __restrict__ bucket_pts, uint32_t nb) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t cnt = counts[b], off = offsets[b];
     G1J acc = G1J::identity();
     for (uint32_t i = 0; i < cnt; ++i) {
-        G1A q = bases[list[off + i]];
+        G1A q = bases[(size_t)list[off + i] * bstride];
         acc = g1_add_affine(acc, q);
     }
     bucket_pts[b] = acc;
@@ -184,6 +184,10 @@ __global__ void msm_set_identity(G1J* out) {
 }
 
 int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, const G1A* d_bases, uint32_t n, G1J* d_out) {
+    return msm_enqueue_strided(s, ws, d_scalars, 8, d_bases, 1, n, d_out);
+}
+
+int msm_enqueue_strided(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, uint32_t sstride, const G1A* d_bases, uint32_t bstride, uint32_t n, G1J* d_out) {
     if (n == 0) {
         hipLaunchKernelGGL(msm_set_identity, dim3(1), dim3(64), 0, s, d_out);
         return 0;
@@ -194,10 +198,10 @@ int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, cons
     if (nb > ws.cap_buckets || (size_t)n * p.windows > ws.cap_list) { set_last_error("msm_enqueue: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, (size_t)nb * 4, s));
     uint32_t gt = (n + 255) / 256;
-    hipLaunchKernelGGL(msm_count_or_scatter<false>, dim3(gt), dim3(256), 0, s, d_scalars, d_bases, n, p, ws.counts, ws.offsets, ws.cursor, ws.list);
+    hipLaunchKernelGGL(msm_count_or_scatter<false>, dim3(gt), dim3(256), 0, s, d_scalars, sstride, d_bases, bstride, n, p, ws.counts, ws.offsets, ws.cursor, ws.list);
     hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, s, ws.counts, ws.offsets, ws.cursor, nb);
-    hipLaunchKernelGGL(msm_count_or_scatter<true>, dim3(gt), dim3(256), 0, s, d_scalars, d_bases, n, p, ws.counts, ws.offsets, ws.cursor, ws.list);
-    hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, d_bases, ws.counts, ws.offsets, ws.list, ws.bucket_pts, nb);
+    hipLaunchKernelGGL(msm_count_or_scatter<true>, dim3(gt), dim3(256), 0, s, d_scalars, sstride, d_bases, bstride, n, p, ws.counts, ws.offsets, ws.cursor, ws.list);
+    hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, d_bases, bstride, ws.counts, ws.offsets, ws.list, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_window, dim3(p.windows), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
     hipLaunchKernelGGL(msm_final, dim3(1), dim3(64), 0, s, ws.window_sums, d_out, p);
     H2V_HIP_CHECK(hipGetLastError());

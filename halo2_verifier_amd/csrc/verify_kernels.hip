@@ -1,0 +1,362 @@
+// Per-proof kernels of the batch verifier: everything verify_proof (lib.rs:33-425) and
+// VerifierSHPLONK::verify_proof (shplonk.rs:175-267) do before the MSMs are evaluated.
+//
+//   k_decompress      one lane per (proof, point)   G1Affine::from_bytes               transcript/mod.rs:158-166
+//   k_check_scalars   one lane per (proof, scalar)  Fr::from_repr canonicity           transcript/mod.rs:168-176
+//   k_stream_build    one lane per (proof, 8-byte word of the absorbed stream)         transcript/mod.rs:216-231
+//   k_transcript      one lane per proof            Blake2b-512 + challenges           transcript/mod.rs:124-133,209-214,500-514
+//   k_multipliers     one workgroup                 suffix products of the batch draws kzg/strategy.rs:129, msm.rs:173-176
+//   k_frvm            one lane per proof            the compiled Fr program            lib.rs:173-346, shplonk.rs:202-264
+//   k_fold_shared     one workgroup per shared base sum over proofs of the scalars of VK-wide bases
+//   k_single_msm      one lane per proof            per-proof channels for SingleStrategy   kzg/strategy.rs:164-176
+//
+// Layouts are chosen so that lanes (= proofs) are contiguous in the fastest dimension for
+// everything the per-proof kernels re-read: stream words [word][proof], challenges [c][proof],
+// program slots [slot][proof], shared scalars [j][proof].
+#include "../../include/h2v.h"
+#include "batch.h"
+
+namespace h2v {
+
+__device__ __forceinline__ void status_set(int* status, uint32_t p, int code) {
+    atomicMin(&status[p], code);  // Transcript (-5) outranks Opening (-4): the reference stops at the first failing read
+}
+
+__global__ void __launch_bounds__(64) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
+                                                   uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, uint8_t* __restrict__ ycanon,
+                                                   int* __restrict__ status) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * np) return;
+    uint32_t p = t / np, slot = t % np;
+    const uint8_t* src = proofs + (size_t)p * proof_len + point_offsets[slot];
+    uint8_t enc[32];
+    for (int i = 0; i < 32; ++i) enc[i] = src[i];
+    G1A a;
+    bool ok = g1_decompress(enc, a);
+    // the identity decodes but cannot be absorbed ("cannot write points at infinity to the transcript")
+    if (!ok || a.is_identity()) { status_set(status, p, slot < n_main_points ? H2V_ERR_TRANSCRIPT : H2V_ERR_OPENING); a = G1A::identity(); }
+    pts[(size_t)p * np + slot] = a;
+    uint8_t yb[32];
+    a.y.to_bytes(yb);
+    uint8_t* dst = ycanon + ((size_t)p * np + slot) * 32;
+    for (int i = 0; i < 32; ++i) dst[i] = yb[i];
+}
+
+__global__ void __launch_bounds__(256) k_check_scalars(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ scalar_offsets,
+                                                       uint32_t ns, const uint8_t* __restrict__ inst, uint32_t ninst, uint32_t n, int* __restrict__ status) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t per = ns + ninst;
+    if (t >= n * per) return;
+    uint32_t p = t / per, i = t % per;
+    const uint8_t* b = i < ns ? proofs + (size_t)p * proof_len + scalar_offsets[i] : inst + ((size_t)p * ninst + (i - ns)) * 32;
+    uint32_t raw[8];
+    for (int j = 0; j < 8; ++j) raw[j] = (uint32_t)b[4 * j] | ((uint32_t)b[4 * j + 1] << 8) | ((uint32_t)b[4 * j + 2] << 16) | ((uint32_t)b[4 * j + 3] << 24);
+    // a non-canonical public input cannot be represented as an Fr on the reference side at all: bad argument for that proof
+    if (Fr::geq_p(raw)) status_set(status, p, i < ns ? H2V_ERR_TRANSCRIPT : H2V_ERR_INVALID_INSTANCES);
+}
+
+__global__ void __launch_bounds__(256) k_stream_build(const TranscriptSrc* __restrict__ stream, uint32_t stream_len, const uint8_t* __restrict__ proofs,
+                                                      uint32_t proof_len, const uint8_t* __restrict__ ycanon, uint32_t np, const uint8_t* __restrict__ inst,
+                                                      uint32_t ninst, uint32_t n, unsigned long long* __restrict__ words) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w = blockIdx.y;
+    if (p >= n) return;
+    unsigned long long v = 0;
+    for (uint32_t b = 0; b < 8; ++b) {
+        uint32_t pos = w * 8 + b;
+        if (pos >= stream_len) break;
+        TranscriptSrc s = stream[pos];  // wave-uniform
+        uint32_t byte;
+        switch (s.kind) {
+            case TranscriptSrc::CONST: byte = s.value; break;
+            case TranscriptSrc::PROOF: byte = proofs[(size_t)p * proof_len + s.offset]; break;
+            case TranscriptSrc::PROOF_MASKED: byte = proofs[(size_t)p * proof_len + s.offset] & 0x3f; break;
+            case TranscriptSrc::YCOORD: byte = ycanon[(size_t)p * np * 32 + s.offset]; break;
+            default: byte = inst[(size_t)p * ninst * 32 + s.offset]; break;
+        }
+        v |= (unsigned long long)byte << (8 * b);
+    }
+    words[(size_t)w * n + p] = v;
+}
+
+// ------------------------------------------------------------------ BLAKE2b (RFC 7693)
+__device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int c) { return (x >> c) | (x << (64 - c)); }
+__constant__ unsigned long long BLAKE_IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                               0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+__constant__ uint8_t BLAKE_SIGMA[12][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+
+__device__ __noinline__ void blake2b_compress(unsigned long long h[8], const unsigned long long m[16], unsigned long long t, bool last) {
+    unsigned long long v[16];
+    for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = BLAKE_IV[i]; }
+    v[12] ^= t;  // t1 = 0: streams are far below 2^64 bytes
+    if (last) v[14] = ~v[14];
+#define H2V_G(a, b, c, d, x, y)                                     \
+    v[a] = v[a] + v[b] + (x); v[d] = rotr64(v[d] ^ v[a], 32);       \
+    v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 24);       \
+    v[a] = v[a] + v[b] + (y); v[d] = rotr64(v[d] ^ v[a], 16);       \
+    v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 63);
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        H2V_G(0, 4, 8, 12, m[BLAKE_SIGMA[r][0]], m[BLAKE_SIGMA[r][1]]);
+        H2V_G(1, 5, 9, 13, m[BLAKE_SIGMA[r][2]], m[BLAKE_SIGMA[r][3]]);
+        H2V_G(2, 6, 10, 14, m[BLAKE_SIGMA[r][4]], m[BLAKE_SIGMA[r][5]]);
+        H2V_G(3, 7, 11, 15, m[BLAKE_SIGMA[r][6]], m[BLAKE_SIGMA[r][7]]);
+        H2V_G(0, 5, 10, 15, m[BLAKE_SIGMA[r][8]], m[BLAKE_SIGMA[r][9]]);
+        H2V_G(1, 6, 11, 12, m[BLAKE_SIGMA[r][10]], m[BLAKE_SIGMA[r][11]]);
+        H2V_G(2, 7, 8, 13, m[BLAKE_SIGMA[r][12]], m[BLAKE_SIGMA[r][13]]);
+        H2V_G(3, 4, 9, 14, m[BLAKE_SIGMA[r][14]], m[BLAKE_SIGMA[r][15]]);
+    }
+#undef H2V_G
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+
+// squeeze_at[q] = absorbed length at which challenge q is produced: digest(stream[0..L)) with the state
+// cloned (transcript/mod.rs:209-214), 64 bytes -> Fr::from_uniform_bytes (:500-514).
+__global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __restrict__ words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
+                                                   uint32_t n, Fr* __restrict__ chal) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    unsigned long long h[8];
+    {   // parameter block: digest 64, no key, fanout = depth = 1, personal "Halo2-Transcript" (transcript/mod.rs:126-129)
+        const unsigned long long pers0 = 0x72542d326f6c6148ULL, pers1 = 0x7470697263736e61ULL;  // "Halo2-Tr" "anscript" little endian
+        for (int i = 0; i < 8; ++i) h[i] = BLAKE_IV[i];
+        h[0] ^= 0x01010040ULL; h[6] ^= pers0; h[7] ^= pers1;
+    }
+    uint32_t blk = 0;
+    for (uint32_t q = 0; q < n_squeeze; ++q) {
+        uint32_t len = squeeze_at[q];  // >= 1
+        uint32_t last_blk = (len - 1) / 128;
+        unsigned long long m[16];
+        for (; blk < last_blk; ++blk) {
+            for (int j = 0; j < 16; ++j) m[j] = words[((size_t)blk * 16 + j) * n + p];
+            blake2b_compress(h, m, (unsigned long long)(blk + 1) * 128, false);
+        }
+        uint32_t rem = len - last_blk * 128;  // 1..128 bytes of the final block
+        for (int j = 0; j < 16; ++j) {
+            unsigned long long w = words[((size_t)last_blk * 16 + j) * n + p];
+            uint32_t lo = 8 * j;
+            if (lo >= rem) w = 0;
+            else if (lo + 8 > rem) w &= (1ULL << (8 * (rem - lo))) - 1;
+            m[j] = w;
+        }
+        unsigned long long hc[8];
+        for (int i = 0; i < 8; ++i) hc[i] = h[i];
+        blake2b_compress(hc, m, len, true);
+        uint32_t w32[16];
+        for (int i = 0; i < 8; ++i) { w32[2 * i] = (uint32_t)hc[i]; w32[2 * i + 1] = (uint32_t)(hc[i] >> 32); }
+        chal[(size_t)q * n + p] = Fr::from_uniform_words(w32);
+    }
+}
+
+// mult[p] = prod_{j > first+p} r_j over the tail of draws; tail[0] is the draw of this shard's proof 0.
+__global__ void __launch_bounds__(1024) k_multipliers(const uint8_t* __restrict__ tail, uint32_t n_tail, uint32_t n, Fr* __restrict__ mult) {
+    __shared__ Fr part[1024];
+    uint32_t t = threadIdx.x;
+    uint32_t chunk = (n_tail + 1023) / 1024;
+    uint32_t lo = min(n_tail, t * chunk), hi = min(n_tail, lo + chunk);
+    Fr prod = Fr::one();
+    for (uint32_t j = lo; j < hi; ++j) { Fr r; Fr::from_bytes(tail + 32 * (size_t)j, r); prod = prod * r; }
+    part[t] = prod;
+    __syncthreads();
+    // inclusive suffix scan: part[t] = prod_{t' >= t} P_t'
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        Fr v = t + d < 1024 ? part[t + d] : Fr::one();
+        __syncthreads();
+        part[t] = part[t] * v;
+        __syncthreads();
+    }
+    Fr run = t + 1 < 1024 ? part[t + 1] : Fr::one();  // product of everything after this lane's chunk
+    for (uint32_t j = hi; j > lo; --j) {
+        if (j - 1 < n) mult[j - 1] = run;
+        Fr r; Fr::from_bytes(tail + 32 * (size_t)(j - 1), r);
+        run = run * r;
+    }
+}
+
+__device__ __forceinline__ Fr slot_load(const Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p) {
+    const uint4* q = reinterpret_cast<const uint4*>(slots + (size_t)s * n + p);
+    uint4 lo = q[0], hi = q[1];
+    Fr r; r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w; r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void slot_store(Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p, const Fr& v) {
+    uint4* q = reinterpret_cast<uint4*>(slots + (size_t)s * n + p);
+    q[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    q[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+}
+
+__global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const uint32_t n = a.n;
+    for (uint32_t pc = 0; pc < a.n_code; ++pc) {
+        const VmInstr in = a.code[pc];  // wave-uniform
+        switch (in.op) {
+            case OP_CONST: slot_store(a.slots, in.d, n, p, a.consts[in.a]); break;
+            case OP_MUL: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p) * slot_load(a.slots, in.b, n, p)); break;
+            case OP_ADD: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p) + slot_load(a.slots, in.b, n, p)); break;
+            case OP_SUB: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p) - slot_load(a.slots, in.b, n, p)); break;
+            case OP_NEG: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p).neg()); break;
+            case OP_INV: {
+                Fr v = slot_load(a.slots, in.a, n, p);
+                if (v.is_zero()) atomicCAS(&a.status[p], 0, H2V_ERR_REFERENCE_PANIC);
+                slot_store(a.slots, in.d, n, p, v.inv());
+                break;
+            }
+            case OP_POW: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p).pow_u32(in.b)); break;
+            case OP_SQRN: {
+                Fr v = slot_load(a.slots, in.a, n, p);
+                for (uint32_t i = 0; i < in.b; ++i) v = v.sqr();
+                slot_store(a.slots, in.d, n, p, v);
+                break;
+            }
+            case OP_LOAD_SCALAR: {
+                const uint8_t* b = a.proofs + (size_t)p * a.proof_len + a.scalar_offsets[in.a];
+                uint8_t tmp[32];
+                for (int i = 0; i < 32; ++i) tmp[i] = b[i];
+                Fr v;
+                if (!Fr::from_bytes(tmp, v)) v = Fr::zero();  // status already set by k_check_scalars
+                slot_store(a.slots, in.d, n, p, v);
+                break;
+            }
+            case OP_LOAD_INST: {
+                const uint8_t* b = a.inst + ((size_t)p * a.ninst + in.a) * 32;
+                uint8_t tmp[32];
+                for (int i = 0; i < 32; ++i) tmp[i] = b[i];
+                Fr v;
+                if (!Fr::from_bytes(tmp, v)) v = Fr::zero();
+                slot_store(a.slots, in.d, n, p, v);
+                break;
+            }
+            case OP_LOAD_CHAL: slot_store(a.slots, in.d, n, p, a.chal[(size_t)in.a * n + p]); break;
+            case OP_LOAD_MULT: slot_store(a.slots, in.d, n, p, a.mult[p]); break;
+            case OP_STORE_MSM: {
+                uint32_t raw[8];
+                slot_load(a.slots, in.a, n, p).to_raw(raw);
+                bool bad = a.status[p] != 0;
+                uint32_t* dst = a.msm_scal + ((size_t)p * a.np + in.b) * 8;
+                for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
+                break;
+            }
+            case OP_STORE_SHARED: {
+                Fr v = slot_load(a.slots, in.a, n, p);
+                if (a.status[p] != 0) v = Fr::zero();
+                a.shared[(size_t)in.b * n + p] = v;
+                break;
+            }
+            case OP_STORE_LEFT: {
+                uint32_t raw[8];
+                slot_load(a.slots, in.a, n, p).to_raw(raw);
+                bool bad = a.status[p] != 0;
+                uint32_t* dst = a.left_scal + (size_t)p * 8;
+                for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+// msm_scal[(n*np + j)] = canonical( sum_p shared[j][p] )
+__global__ void __launch_bounds__(256) k_fold_shared(const Fr* __restrict__ shared, uint32_t n, uint32_t np, uint32_t* __restrict__ msm_scal) {
+    __shared__ Fr red[256];
+    uint32_t j = blockIdx.x, t = threadIdx.x;
+    Fr acc = Fr::zero();
+    for (uint32_t p = t; p < n; p += 256) acc = acc + shared[(size_t)j * n + p];
+    red[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (t < d) red[t] = red[t] + red[t + d];
+        __syncthreads();
+    }
+    if (t == 0) {
+        uint32_t raw[8]; red[0].to_raw(raw);
+        uint32_t* dst = msm_scal + ((size_t)n * np + j) * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = raw[i];
+    }
+}
+
+// SingleStrategy: each proof's own two channels (left = h2, right = its full Guard MSM), no pooling.
+__global__ void __launch_bounds__(64) k_single_msm(const uint32_t* __restrict__ msm_scal, const Fr* __restrict__ shared, const G1A* __restrict__ pts,
+                                                   uint32_t n, uint32_t np, uint32_t n_shared, uint32_t slot_h2, G1J* __restrict__ pairs) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const G1A* shared_bases = pts + (size_t)n * np;
+    G1J acc = G1J::identity();
+    for (int bit = 253; bit >= 0; --bit) {
+        acc = g1_dbl(acc);
+        for (uint32_t s = 0; s < np; ++s) {
+            uint32_t w = msm_scal[((size_t)p * np + s) * 8 + (bit >> 5)];
+            if ((w >> (bit & 31)) & 1) acc = g1_add_affine(acc, pts[(size_t)p * np + s]);
+        }
+    }
+    // shared bases: scalars are Montgomery in shared[j][p]
+    for (uint32_t j = 0; j < n_shared; ++j) {
+        uint32_t raw[8];
+        shared[(size_t)j * n + p].to_raw(raw);
+        G1J t = G1J::identity();
+        for (int bit = 253; bit >= 0; --bit) {
+            t = g1_dbl(t);
+            if ((raw[bit >> 5] >> (bit & 31)) & 1) t = g1_add_affine(t, shared_bases[j]);
+        }
+        acc = g1_add(acc, t);
+    }
+    pairs[2 * (size_t)p] = G1J::from_affine(pts[(size_t)p * np + slot_h2]);
+    pairs[2 * (size_t)p + 1] = acc;
+}
+
+// ------------------------------------------------------------------ launchers
+int decompress_stage_enqueue(hipStream_t s, const StageArgs& g) {
+    const uint32_t n = g.n;
+    if (!n) return 0;
+    const Plan& pl = *g.plan;
+    H2V_HIP_CHECK(hipMemsetAsync(g.status, 0, sizeof(int) * n, s));
+    uint32_t tp = n * pl.n_points;
+    hipLaunchKernelGGL(k_decompress, dim3((tp + 63) / 64), dim3(64), 0, s, g.proofs, pl.proof_len, g.pd->point_offsets, pl.n_points, pl.n_main_points, n, g.pts, g.ycanon, g.status);
+    uint32_t ts = n * (pl.n_scalars + pl.n_instance_values);
+    if (ts) hipLaunchKernelGGL(k_check_scalars, dim3((ts + 255) / 256), dim3(256), 0, s, g.proofs, pl.proof_len, g.pd->scalar_offsets, pl.n_scalars, g.inst, pl.n_instance_values, n, g.status);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
+    const uint32_t n = g.n;
+    if (!n) return 0;
+    const Plan& pl = *g.plan;
+    uint32_t stream_len = (uint32_t)pl.stream.size();
+    uint32_t n_words = g.stream_words;
+    hipLaunchKernelGGL(k_stream_build, dim3((n + 255) / 256, n_words), dim3(256), 0, s, g.pd->stream, stream_len, g.proofs, pl.proof_len, g.ycanon, pl.n_points, g.inst, pl.n_instance_values, n, g.words);
+    hipLaunchKernelGGL(k_transcript, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, Fr* d_mult) {
+    hipLaunchKernelGGL(k_multipliers, dim3(1), dim3(1024), 0, s, d_tail, n_tail, n, d_mult);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int frvm_enqueue(hipStream_t s, const FrvmArgs& a) {
+    if (!a.n) return 0;
+    hipLaunchKernelGGL(k_frvm, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t* d_msm_scal) {
+    if (!n_shared) return 0;
+    hipLaunchKernelGGL(k_fold_shared, dim3(n_shared), dim3(256), 0, s, d_shared, n, np, d_msm_scal);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t slot_h2, G1J* d_pairs) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_single_msm, dim3((n + 63) / 64), dim3(64), 0, s, d_msm_scal, d_shared, d_pts, n, np, n_shared, slot_h2, d_pairs);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace h2v

@@ -1,0 +1,117 @@
+// Per-VK host data model and the compiled "verification plan".
+//
+// The reference re-derives everything below for every proof inside verify_proof (query list,
+// rotation sets, which evaluation feeds which expression).  All of it depends only on the
+// VerifyingKey, so it is compiled once per context into:
+//   * the proof layout        (byte offset of every point / scalar the transcript reads, lib.rs:91-253, shplonk.rs:195-200)
+//   * the transcript stream   (which bytes Blake2b absorbs, where challenges are squeezed, transcript/mod.rs:205-232)
+//   * a straight-line Fr program (expression evaluation lib.rs:273-346 + SHPLONK scalar preparation shplonk.rs:202-264)
+//     executed by a SIMT interpreter with one proof per lane
+//   * the MSM term map        (which point slot / shared base each output scalar multiplies)
+#pragma once
+#include "ctx.h"
+#include <map>
+#include <mutex>
+
+namespace h2v {
+
+// ---------------------------------------------------------------- VK data model (plonk/vk.rs:16-26,173-211)
+static const uint8_t COL_INSTANCE = 254, COL_FIXED = 255;  // 0..2 = advice phase (plonk/circuit.rs:36-65)
+struct ColumnH { uint32_t index; uint8_t type; };
+struct QueryH { ColumnH column; int32_t rotation; };
+struct TermH { uint16_t coeff_idx; std::vector<std::pair<uint32_t, uint32_t>> factors; };
+struct ExprH { uint32_t num_vars = 0; std::vector<TermH> terms; };
+struct LookupH { std::vector<ExprH> input, table; };
+struct ShuffleH { std::vector<ExprH> input, shuffle; };
+
+struct VkHost {
+    uint32_t k = 0, cs_degree = 0;
+    std::vector<G1A> fixed_commitments, permutation_commitments;
+    Fr transcript_repr;
+    uint32_t num_fixed_columns = 0, num_advice_columns = 0, num_instance_columns = 0, num_selectors = 0, num_challenges = 0;
+    std::vector<uint8_t> advice_column_phase, challenge_phase;
+    std::vector<uint32_t> num_advice_queries;
+    std::vector<QueryH> advice_queries, instance_queries, fixed_queries;
+    std::vector<ColumnH> permutation_columns;
+    std::vector<ExprH> gates;
+    std::vector<LookupH> lookups;
+    std::vector<ShuffleH> shuffles;
+    std::vector<Fr> coeff_vals;
+    size_t blinding_factors() const;  // plonk/vk.rs:396-401
+};
+// VerifyingKey::read (plonk/vk.rs:76-115, 274-365); false + message when the bytes are rejected
+bool vk_from_bytes(const uint8_t* data, size_t len, int format, VkHost& out, std::string& err);
+
+// ---------------------------------------------------------------- Fr program
+enum VmOp : uint32_t {
+    OP_CONST = 1,      // d <- consts[a]
+    OP_MUL = 2,        // d <- a * b
+    OP_ADD = 3,
+    OP_SUB = 4,
+    OP_NEG = 5,        // d <- -a
+    OP_INV = 6,        // d <- 1/a ; a == 0 sets the proof's status to H2V_ERR_REFERENCE_PANIC
+    OP_POW = 7,        // d <- a ^ b (b immediate)
+    OP_SQRN = 8,       // d <- a ^ (2^b) (b immediate)
+    OP_LOAD_SCALAR = 9,   // d <- proof scalar #a
+    OP_LOAD_INST = 10,    // d <- instance value #a (flat index over the proof's instance columns)
+    OP_LOAD_CHAL = 11,    // d <- challenge #a
+    OP_LOAD_MULT = 12,    // d <- batch multiplier of this proof
+    OP_STORE_MSM = 13,    // msm_scalars[proof][point slot b] <- canonical(a)
+    OP_STORE_SHARED = 14, // shared[proof][b] <- a (Montgomery)
+    OP_STORE_LEFT = 15,   // left_scalars[proof] <- canonical(a)
+};
+struct VmInstr { uint32_t op, d, a, b; };
+
+struct TranscriptSrc {  // one byte of the absorbed stream
+    enum Kind : uint8_t { CONST = 0, PROOF = 1, PROOF_MASKED = 2, YCOORD = 3, INSTANCE = 4 };
+    uint8_t kind; uint8_t value; uint32_t offset;
+};
+
+struct Plan {
+    // proof layout
+    uint32_t n_points = 0, n_scalars = 0, proof_len = 0;
+    std::vector<uint32_t> point_offsets, scalar_offsets;  // byte offsets into the proof
+    uint32_t n_main_points = 0;                           // points read before the multi-open part (errors there are Transcript, after: Opening)
+    uint32_t slot_h1 = 0, slot_h2 = 0;
+    // transcript
+    std::vector<TranscriptSrc> stream;     // absorbed byte stream incl. the 0x00 challenge markers
+    std::vector<uint32_t> squeeze_at;      // stream length at which challenge i is squeezed
+    uint32_t n_challenges = 0;             // user challenges + theta, beta, gamma, y, x, y', v, u
+    uint32_t n_user_challenges = 0;
+    // program
+    std::vector<VmInstr> code;
+    std::vector<Fr> consts;
+    uint32_t n_slots = 0;
+    // MSM map
+    uint32_t n_shared = 0;                  // fixed (queried) + permutation + g
+    std::vector<G1A> shared_bases;
+    // reference term order of the right channel (shplonk.rs:256-264): (is_shared, index)
+    std::vector<std::pair<uint8_t, uint32_t>> right_term_order;
+    // instance shape this plan was compiled for
+    std::vector<size_t> col_lens;
+    uint32_t n_instance_values = 0;
+};
+// Returns 0 or an H2V error code (InstanceTooLarge, ReferencePanic for an empty gate polynomial, ...)
+int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, Plan& out, std::string& err);
+
+struct PlanDevice {
+    Plan host;
+    VmInstr* code = nullptr;
+    Fr* consts = nullptr;
+    TranscriptSrc* stream = nullptr;
+    uint32_t* squeeze_at = nullptr;
+    uint32_t* point_offsets = nullptr;
+    uint32_t* scalar_offsets = nullptr;
+    G1A* shared_bases = nullptr;
+    int upload();
+    void release();
+};
+
+struct VkDevice {
+    VkHost vk;
+    std::map<std::vector<size_t>, PlanDevice*> plans;  // keyed by instance column lengths
+    std::mutex mu;
+};
+int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice** out);
+
+}  // namespace h2v

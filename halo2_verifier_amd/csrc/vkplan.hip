@@ -1,0 +1,739 @@
+// Host side: VerifyingKey ingestion and compilation of the per-VK verification plan
+// (see vkplan.h).  Pure host code; compiled by hipcc because it shares bn254.cuh with the kernels.
+#include "../../include/h2v.h"
+#include "ctx.h"
+#include "vkplan.h"
+#include <algorithm>
+#include <array>
+#include <set>
+#include <string.h>
+
+namespace h2v {
+
+// =============================================================================== VK parsing
+namespace {
+struct Reader {
+    const uint8_t* d; size_t n, pos = 0; bool ok = true;
+    Reader(const uint8_t* p, size_t len) : d(p), n(len) {}
+    const uint8_t* take(size_t k) {
+        static const uint8_t zeros[128] = {0};
+        if (pos + k > n) { ok = false; return zeros; }
+        const uint8_t* r = d + pos; pos += k; return r;
+    }
+    uint8_t u8() { return *take(1); }
+    uint16_t u16() { const uint8_t* b = take(2); return (uint16_t)((b[0] << 8) | b[1]); }            // helpers.rs:121-125 (big endian)
+    uint32_t u32() { const uint8_t* b = take(4); return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; }
+    int32_t i32() { return (int32_t)u32(); }
+};
+
+template <class F> bool field_from_mont_bytes(const uint8_t* b, F& x) {
+    for (int i = 0; i < 8; ++i) x.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    return !F::geq_p(x.v);
+}
+bool read_fr(Reader& r, int fmt, Fr& x, std::string& err) {
+    const uint8_t* b = r.take(32);
+    if (fmt == H2V_SERDE_PROCESSED) { if (!Fr::from_bytes(b, x)) { err = "Invalid prime field point encoding"; return false; } return true; }
+    bool ok = field_from_mont_bytes(b, x);
+    if (!ok && fmt == H2V_SERDE_RAW_BYTES) { err = "Invalid prime field point encoding"; return false; }
+    return true;
+}
+bool read_g1(Reader& r, int fmt, G1A& p, std::string& err) {
+    if (fmt == H2V_SERDE_PROCESSED) {
+        if (!g1_decompress(r.take(32), p)) { err = "Invalid point encoding in proof"; return false; }
+        return true;
+    }
+    const uint8_t* b = r.take(64);
+    bool ok = field_from_mont_bytes(b, p.x) & field_from_mont_bytes(b + 32, p.y);
+    if (fmt == H2V_SERDE_RAW_BYTES && (!ok || !p.on_curve())) { err = "invalid uncompressed point"; return false; }
+    return true;
+}
+bool read_expr(Reader& r, ExprH& e) {
+    e.num_vars = r.u32();
+    uint32_t nt = r.u32();
+    if (!r.ok || nt > (1u << 24)) return false;
+    e.terms.resize(nt);
+    for (auto& t : e.terms) {
+        t.coeff_idx = r.u16();
+        uint32_t nf = r.u32();
+        if (!r.ok || nf > (1u << 20)) return false;
+        t.factors.resize(nf);
+        for (auto& f : t.factors) { f.first = r.u32(); f.second = r.u32(); }
+    }
+    return r.ok;
+}
+}  // namespace
+
+size_t VkHost::blinding_factors() const {
+    size_t f = 1;
+    if (!num_advice_queries.empty()) { f = 0; for (uint32_t q : num_advice_queries) if (q > f) f = q; }
+    if (f < 3) f = 3;
+    return f + 2;
+}
+
+bool vk_from_bytes(const uint8_t* data, size_t len, int fmt, VkHost& vk, std::string& err) {
+    if (fmt < 0 || fmt > 2) { err = "unknown serde format"; return false; }
+    Reader r(data, len);
+    const uint32_t LIM = 1u << 20;
+    vk.k = r.u32();
+    uint32_t nfix = r.u32();
+    if (!r.ok || vk.k > 28 || nfix > LIM) { err = "failed to fill whole buffer"; return false; }
+    vk.fixed_commitments.resize(nfix);
+    for (auto& c : vk.fixed_commitments) if (!read_g1(r, fmt, c, err)) return false;
+    vk.cs_degree = r.u32();
+    vk.num_fixed_columns = r.u32(); vk.num_advice_columns = r.u32(); vk.num_instance_columns = r.u32();
+    vk.num_selectors = r.u32(); vk.num_challenges = r.u32();
+    uint32_t ng = r.u32(), nl = r.u32(), ns = r.u32(), nc = r.u32();
+    if (!r.ok || vk.num_fixed_columns > LIM || vk.num_advice_columns > LIM || vk.num_instance_columns > LIM || vk.num_challenges > LIM || ng > LIM || nl > LIM || ns > LIM || nc > 65536 * 16) { err = "failed to fill whole buffer"; return false; }
+    for (uint32_t i = 0; i < vk.num_advice_columns; ++i) vk.advice_column_phase.push_back(r.u8());
+    for (uint32_t i = 0; i < vk.num_challenges; ++i) vk.challenge_phase.push_back(r.u8());
+    size_t total = 0;
+    for (uint32_t i = 0; i < vk.num_advice_columns; ++i) { vk.num_advice_queries.push_back(r.u32()); total += vk.num_advice_queries.back(); }
+    if (!r.ok || total > LIM) { err = "failed to fill whole buffer"; return false; }
+    for (size_t i = 0; i < total; ++i) { QueryH q; q.column.index = r.u32(); q.column.type = r.u8(); q.rotation = r.i32(); vk.advice_queries.push_back(q); }
+    // the reader takes the instance / fixed query counts from the column counts (plonk/vk.rs:310-322)
+    for (uint32_t i = 0; i < vk.num_instance_columns; ++i) { QueryH q; q.column.index = r.u32(); q.column.type = COL_INSTANCE; q.rotation = r.i32(); vk.instance_queries.push_back(q); }
+    for (uint32_t i = 0; i < vk.num_fixed_columns; ++i) { QueryH q; q.column.index = r.u32(); q.column.type = COL_FIXED; q.rotation = r.i32(); vk.fixed_queries.push_back(q); }
+    uint32_t np = r.u32();
+    if (!r.ok || np > LIM) { err = "failed to fill whole buffer"; return false; }
+    for (uint32_t i = 0; i < np; ++i) {
+        ColumnH c; c.index = r.u32(); c.type = r.u8();
+        if (!(c.type <= 2 || c.type >= 254)) { err = "Invalid phase for advice column"; return false; }  // plonk/circuit.rs:52-61
+        vk.permutation_columns.push_back(c);
+    }
+    vk.gates.resize(ng);
+    for (auto& g : vk.gates) if (!read_expr(r, g)) { err = "failed to fill whole buffer"; return false; }
+    vk.lookups.resize(nl);
+    for (auto& a : vk.lookups) {  // reader order: input, table interleaved (plonk/lookup.rs:51-68)
+        uint32_t m = r.u32();
+        if (!r.ok || m > LIM) { err = "failed to fill whole buffer"; return false; }
+        a.input.resize(m); a.table.resize(m);
+        for (uint32_t j = 0; j < m; ++j) if (!read_expr(r, a.input[j]) || !read_expr(r, a.table[j])) { err = "failed to fill whole buffer"; return false; }
+    }
+    vk.shuffles.resize(ns);
+    for (auto& a : vk.shuffles) {  // plonk/shuffle.rs:86-102
+        uint32_t m = r.u32();
+        if (!r.ok || m > LIM) { err = "failed to fill whole buffer"; return false; }
+        a.input.resize(m); a.shuffle.resize(m);
+        for (uint32_t j = 0; j < m; ++j) if (!read_expr(r, a.input[j]) || !read_expr(r, a.shuffle[j])) { err = "failed to fill whole buffer"; return false; }
+    }
+    vk.coeff_vals.resize(nc);
+    for (auto& c : vk.coeff_vals) if (!read_fr(r, fmt, c, err)) return false;
+    vk.permutation_commitments.resize(vk.permutation_columns.size());
+    for (auto& c : vk.permutation_commitments) if (!read_g1(r, fmt, c, err)) return false;
+    size_t sel_bytes = (((size_t)1 << vk.k) + 7) / 8;
+    for (uint32_t i = 0; i < vk.num_selectors; ++i) r.take(sel_bytes);  // selector bitmaps: unused by verification
+    if (!read_fr(r, fmt, vk.transcript_repr, err)) return false;
+    if (!r.ok) { err = "failed to fill whole buffer"; return false; }
+    if (vk.cs_degree < 3) { err = "cs_degree below the permutation argument's minimum of 3"; return false; }
+    return true;
+}
+
+// =============================================================================== program builder
+namespace {
+typedef uint32_t Val;  // SSA value id
+struct Node { uint32_t op; Val a, b; uint32_t imm; bool has_result; };
+
+struct Builder {
+    std::vector<Node> nodes;
+    std::vector<Fr> consts;
+    std::map<std::array<uint32_t, 8>, Val> const_node;
+    std::vector<int64_t> const_of;  // node id -> const index or -1
+    std::map<uint32_t, Val> scalar_node, inst_node, chal_node;
+    Val mult_node = (Val)-1;
+
+    Val push(uint32_t op, Val a, Val b, uint32_t imm, bool res, int64_t cidx = -1) {
+        nodes.push_back({op, a, b, imm, res}); const_of.push_back(cidx);
+        return (Val)nodes.size() - 1;
+    }
+    bool is_const(Val v) const { return const_of[v] >= 0; }
+    const Fr& cval(Val v) const { return consts[(size_t)const_of[v]]; }
+    Val cst(const Fr& f) {
+        std::array<uint32_t, 8> key; for (int i = 0; i < 8; ++i) key[i] = f.v[i];
+        auto it = const_node.find(key);
+        if (it != const_node.end()) return it->second;
+        consts.push_back(f);
+        Val v = push(OP_CONST, 0, 0, (uint32_t)consts.size() - 1, true, (int64_t)consts.size() - 1);
+        const_node[key] = v;
+        return v;
+    }
+    Val zero() { return cst(Fr::zero()); }
+    Val one() { return cst(Fr::one()); }
+    Val mul(Val a, Val b) {
+        if (is_const(a) && is_const(b)) return cst(cval(a) * cval(b));
+        if (is_const(a) && cval(a) == Fr::one()) return b;
+        if (is_const(b) && cval(b) == Fr::one()) return a;
+        if ((is_const(a) && cval(a).is_zero()) || (is_const(b) && cval(b).is_zero())) return zero();
+        return push(OP_MUL, a, b, 0, true);
+    }
+    Val add(Val a, Val b) {
+        if (is_const(a) && is_const(b)) return cst(cval(a) + cval(b));
+        if (is_const(a) && cval(a).is_zero()) return b;
+        if (is_const(b) && cval(b).is_zero()) return a;
+        return push(OP_ADD, a, b, 0, true);
+    }
+    Val sub(Val a, Val b) {
+        if (is_const(a) && is_const(b)) return cst(cval(a) - cval(b));
+        if (is_const(b) && cval(b).is_zero()) return a;
+        return push(OP_SUB, a, b, 0, true);
+    }
+    Val neg(Val a) { if (is_const(a)) return cst(cval(a).neg()); return push(OP_NEG, a, 0, 0, true); }
+    Val sqr(Val a) { return mul(a, a); }
+    Val inv(Val a) { return push(OP_INV, a, 0, 0, true); }
+    Val pow(Val a, uint32_t e) {
+        if (e == 0) return one();
+        if (e == 1) return a;
+        if (is_const(a)) return cst(cval(a).pow_u32(e));
+        if (e == 2) return mul(a, a);
+        return push(OP_POW, a, 0, e, true);
+    }
+    Val sqrn(Val a, uint32_t k) { if (k == 0) return a; return push(OP_SQRN, a, 0, k, true); }
+    Val load_scalar(uint32_t i) { auto it = scalar_node.find(i); if (it != scalar_node.end()) return it->second; return scalar_node[i] = push(OP_LOAD_SCALAR, 0, 0, i, true); }
+    Val load_inst(uint32_t i) { auto it = inst_node.find(i); if (it != inst_node.end()) return it->second; return inst_node[i] = push(OP_LOAD_INST, 0, 0, i, true); }
+    Val load_chal(uint32_t i) { auto it = chal_node.find(i); if (it != chal_node.end()) return it->second; return chal_node[i] = push(OP_LOAD_CHAL, 0, 0, i, true); }
+    Val load_mult() { if (mult_node == (Val)-1) mult_node = push(OP_LOAD_MULT, 0, 0, 0, true); return mult_node; }
+    void store_msm(Val a, uint32_t slot) { push(OP_STORE_MSM, a, 0, slot, false); }
+    void store_shared(Val a, uint32_t j) { push(OP_STORE_SHARED, a, 0, j, false); }
+    void store_left(Val a) { push(OP_STORE_LEFT, a, 0, 0, false); }
+
+    // values[i] <- 1 / values[i] for all i with ONE inversion (Montgomery's trick)
+    void batch_invert(std::vector<Val>& vals) {
+        if (vals.empty()) return;
+        std::vector<Val> prefix(vals.size());
+        prefix[0] = vals[0];
+        for (size_t i = 1; i < vals.size(); ++i) prefix[i] = mul(prefix[i - 1], vals[i]);
+        Val run = inv(prefix.back());
+        for (size_t i = vals.size(); i-- > 1;) {
+            Val r = mul(run, prefix[i - 1]);
+            run = mul(run, vals[i]);
+            vals[i] = r;
+        }
+        vals[0] = run;
+    }
+
+    // liveness-based slot assignment; emits the final instruction stream
+    void emit(std::vector<VmInstr>& code, uint32_t& n_slots) const {
+        size_t n = nodes.size();
+        std::vector<size_t> last_use(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes[i];
+            auto use = [&](Val v) { last_use[v] = std::max(last_use[v], i); };
+            switch (nd.op) {
+                case OP_MUL: case OP_ADD: case OP_SUB: use(nd.a); use(nd.b); break;
+                case OP_NEG: case OP_INV: case OP_POW: case OP_SQRN: case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: use(nd.a); break;
+                default: break;
+            }
+        }
+        std::vector<uint32_t> slot(n, 0), free_list;
+        std::vector<std::vector<Val>> dying(n);
+        for (size_t v = 0; v < n; ++v) if (nodes[v].has_result) dying[std::max(last_use[v], v)].push_back((Val)v);
+        uint32_t next = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const Node& nd = nodes[i];
+            VmInstr in{nd.op, 0, 0, 0};
+            switch (nd.op) {
+                case OP_MUL: case OP_ADD: case OP_SUB: in.a = slot[nd.a]; in.b = slot[nd.b]; break;
+                case OP_NEG: case OP_INV: in.a = slot[nd.a]; break;
+                case OP_POW: case OP_SQRN: in.a = slot[nd.a]; in.b = nd.imm; break;
+                case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: in.a = slot[nd.a]; in.b = nd.imm; break;
+                default: in.a = nd.imm; break;  // CONST / LOAD_*
+            }
+            if (nd.has_result) {
+                // the destination may not alias a source that is read in the same instruction after being
+                // written; the interpreter reads both operands before it writes, so reuse is safe even then
+                uint32_t s;
+                if (!free_list.empty()) { s = free_list.back(); free_list.pop_back(); } else s = next++;
+                slot[i] = s; in.d = s;
+            }
+            code.push_back(in);
+            for (Val v : dying[i]) free_list.push_back(slot[v]);
+        }
+        n_slots = next ? next : 1;
+    }
+};
+
+enum CommitKind { K_ADVICE, K_PERM_PRODUCT, K_LOOKUP, K_SHUFFLE, K_FIXED, K_PERM_COMMON, K_H_MSM, K_RANDOM };
+struct CommitRef {
+    int kind, idx;
+    bool operator==(const CommitRef& o) const { return kind == o.kind && idx == o.idx; }
+};
+struct SymQuery { CommitRef c; int64_t rot; Val eval; };  // point = x * omega^rot (rot normalised mod n)
+}  // namespace
+
+// =============================================================================== plan compiler
+int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, Plan& plan, std::string& err) {
+    if (col_lens.size() != vk.num_instance_columns) { err = "instances do not match the VK's instance column count"; return H2V_ERR_INVALID_INSTANCES; }
+    if (params.k != vk.k) { err = "params.k differs from vk.k"; return H2V_ERR_BAD_ARGUMENT; }
+    const uint64_t n = 1ULL << vk.k;
+    size_t total_inst = 0;
+    for (size_t l : col_lens) total_inst += l;
+    if (total_inst > 4096) { err = "more than 4096 instance values per proof are not supported by this build"; return H2V_ERR_INSTANCE_TOO_LARGE; }
+    for (size_t l : col_lens) if (l > n) { err = "instance column longer than the domain"; return H2V_ERR_INSTANCE_TOO_LARGE; }
+    plan.col_lens = col_lens; plan.n_instance_values = (uint32_t)total_inst;
+
+    const size_t A = vk.num_advice_columns, L = vk.lookups.size(), Sh = vk.shuffles.size(), P = vk.permutation_columns.size();
+    const size_t chunk = vk.cs_degree - 2, nsets = P == 0 ? 0 : (P + chunk - 1) / chunk, H = vk.cs_degree - 1;
+    const size_t Qa = vk.advice_queries.size(), Qf = vk.fixed_queries.size(), Ch = vk.num_challenges;
+    const size_t bf = vk.blinding_factors();
+    uint8_t max_phase = 0;
+    for (uint8_t p : vk.advice_column_phase) max_phase = std::max(max_phase, p);
+    if (vk.advice_column_phase.size() != A || vk.challenge_phase.size() != Ch || vk.fixed_commitments.size() < vk.num_fixed_columns) { err = "inconsistent VK"; return H2V_ERR_FORMAT; }
+
+    // ---------------- domain constants (poly/domain.rs:34-140)
+    Fr omega;
+    {
+        // ROOT_OF_UNITY = 7^((r-1)/2^28); omega = ROOT_OF_UNITY^(2^(28-k))
+        uint32_t e[8]; for (int i = 0; i < 8; ++i) e[i] = FrParams::P(i);
+        e[0] -= 1;
+        for (int i = 0; i < 8; ++i) e[i] = (e[i] >> 28) | (i < 7 ? (e[i + 1] << 4) : 0);
+        omega = Fr::from_u32(7).pow_limbs(e);
+        for (uint32_t i = vk.k; i < 28; ++i) omega = omega.sqr();
+    }
+    const Fr omega_inv = omega.inv();
+    const Fr n_inv = Fr::from_u32((uint32_t)n).inv();  // k <= 28
+    Fr delta = Fr::from_u32(7);
+    for (int i = 0; i < 28; ++i) delta = delta.sqr();  // DELTA = 7^(2^28)
+    auto omega_pow = [&](int64_t r) {
+        Fr base = r >= 0 ? omega : omega_inv;
+        uint64_t e = (uint64_t)(r >= 0 ? r : -r);
+        Fr acc = Fr::one();
+        for (int i = 63; i >= 0; --i) { acc = acc.sqr(); if ((e >> i) & 1) acc = acc * base; }
+        return acc;
+    };
+    auto norm_rot = [&](int64_t r) { int64_t m = (int64_t)n; return ((r % m) + m) % m; };
+
+    // ---------------- proof layout + transcript stream
+    std::vector<uint32_t> advice_slot(A, 0), lk_input_slot(L), lk_table_slot(L), lk_product_slot(L), sh_slot(Sh), perm_slot(nsets), h_slot(H);
+    uint32_t random_slot = 0;
+    uint32_t np = 0, nsc = 0, off = 0;
+    std::vector<uint32_t> squeeze_order;  // challenge id of each squeeze
+    auto emit_const = [&](uint8_t b) { plan.stream.push_back({TranscriptSrc::CONST, b, 0}); };
+    auto absorb_point = [&]() -> uint32_t {
+        uint32_t slot = np++;
+        plan.point_offsets.push_back(off);
+        emit_const(1);
+        for (uint32_t i = 0; i < 32; ++i) plan.stream.push_back({(uint8_t)(i == 31 ? TranscriptSrc::PROOF_MASKED : TranscriptSrc::PROOF), 0, off + i});
+        for (uint32_t i = 0; i < 32; ++i) plan.stream.push_back({TranscriptSrc::YCOORD, 0, slot * 32 + i});
+        off += 32;
+        return slot;
+    };
+    auto absorb_scalar = [&]() -> uint32_t {
+        uint32_t idx = nsc++;
+        plan.scalar_offsets.push_back(off);
+        emit_const(2);
+        for (uint32_t i = 0; i < 32; ++i) plan.stream.push_back({TranscriptSrc::PROOF, 0, off + i});
+        off += 32;
+        return idx;
+    };
+    auto squeeze = [&](uint32_t chal_id) {
+        emit_const(0);
+        plan.squeeze_at.push_back((uint32_t)plan.stream.size());
+        squeeze_order.push_back(chal_id);
+    };
+    const uint32_t C_THETA = (uint32_t)Ch, C_BETA = C_THETA + 1, C_GAMMA = C_THETA + 2, C_Y = C_THETA + 3, C_X = C_THETA + 4, C_SY = C_THETA + 5, C_SV = C_THETA + 6, C_SU = C_THETA + 7;
+    plan.n_user_challenges = (uint32_t)Ch; plan.n_challenges = C_SU + 1;
+    {   // vk.hash_into + instances (plonk/vk.rs:145-152, lib.rs:76-82)
+        uint8_t repr[32]; vk.transcript_repr.to_bytes(repr);
+        emit_const(2);
+        for (int i = 0; i < 32; ++i) emit_const(repr[i]);
+        for (uint32_t v = 0; v < total_inst; ++v) { emit_const(2); for (uint32_t i = 0; i < 32; ++i) plan.stream.push_back({TranscriptSrc::INSTANCE, 0, v * 32 + i}); }
+    }
+    for (unsigned phase = 0; phase <= max_phase; ++phase) {  // lib.rs:91-109
+        for (size_t i = 0; i < A; ++i) if (vk.advice_column_phase[i] == phase) advice_slot[i] = absorb_point();
+        for (size_t i = 0; i < Ch; ++i) if (vk.challenge_phase[i] == phase) squeeze((uint32_t)i);
+    }
+    squeeze(C_THETA);
+    for (size_t i = 0; i < L; ++i) { lk_input_slot[i] = absorb_point(); lk_table_slot[i] = absorb_point(); }
+    squeeze(C_BETA); squeeze(C_GAMMA);
+    for (size_t i = 0; i < nsets; ++i) perm_slot[i] = absorb_point();
+    for (size_t i = 0; i < L; ++i) lk_product_slot[i] = absorb_point();
+    for (size_t i = 0; i < Sh; ++i) sh_slot[i] = absorb_point();
+    random_slot = absorb_point();
+    squeeze(C_Y);
+    for (size_t i = 0; i < H; ++i) h_slot[i] = absorb_point();
+    squeeze(C_X);
+    // evaluations (lib.rs:220-253)
+    std::vector<uint32_t> s_adv(Qa), s_fix(Qf), s_sigma(P);
+    for (auto& s : s_adv) s = absorb_scalar();
+    for (auto& s : s_fix) s = absorb_scalar();
+    uint32_t s_random = absorb_scalar();
+    for (auto& s : s_sigma) s = absorb_scalar();
+    struct PS { uint32_t eval, next, last; bool has_last; };
+    std::vector<PS> s_perm(nsets);
+    for (size_t i = 0; i < nsets; ++i) {
+        s_perm[i].eval = absorb_scalar(); s_perm[i].next = absorb_scalar();
+        s_perm[i].has_last = i + 1 < nsets;
+        s_perm[i].last = s_perm[i].has_last ? absorb_scalar() : 0;
+    }
+    struct LS { uint32_t product, product_next, input, input_inv, table; };
+    std::vector<LS> s_lk(L);
+    for (auto& s : s_lk) { s.product = absorb_scalar(); s.product_next = absorb_scalar(); s.input = absorb_scalar(); s.input_inv = absorb_scalar(); s.table = absorb_scalar(); }
+    struct SS { uint32_t product, product_next; };
+    std::vector<SS> s_sh(Sh);
+    for (auto& s : s_sh) { s.product = absorb_scalar(); s.product_next = absorb_scalar(); }
+    plan.n_main_points = np;
+    squeeze(C_SY); squeeze(C_SV);
+    plan.slot_h1 = absorb_point();
+    squeeze(C_SU);
+    plan.slot_h2 = absorb_point();
+    plan.n_points = np; plan.n_scalars = nsc; plan.proof_len = off;
+    // challenge id -> position in squeeze order
+    std::vector<uint32_t> sq_of(plan.n_challenges, 0);
+    for (size_t q = 0; q < squeeze_order.size(); ++q) sq_of[squeeze_order[q]] = (uint32_t)q;
+
+    // ---------------- the Fr program
+    Builder b;
+    auto chal = [&](uint32_t id) { return b.load_chal(sq_of[id]); };
+    std::vector<Val> user_ch(Ch);
+    for (size_t i = 0; i < Ch; ++i) user_ch[i] = chal((uint32_t)i);
+    Val theta = chal(C_THETA), beta = chal(C_BETA), gamma = chal(C_GAMMA), y = chal(C_Y), x = chal(C_X), sy = chal(C_SY), sv = chal(C_SV), su = chal(C_SU);
+    Val xn = b.sqrn(x, vk.k);  // x^n, n = 2^k   (lib.rs:180,259)
+    Val xn_m1 = b.sub(xn, b.one());
+
+    // every inversion of the proof goes through one batch inversion
+    //   [0] xn - 1 (vanishing.rs:100)  [1] x (interpolation denominators)  [2] z_diff_0 (shplonk.rs:215)  [3..] x - omega^i
+    std::map<int64_t, size_t> l_index;  // normalised rotation -> position in `dens`
+    std::vector<int64_t> l_rots;
+    auto need_l = [&](int64_t r) { int64_t k2 = norm_rot(r); if (!l_index.count(k2)) { l_index[k2] = l_rots.size(); l_rots.push_back(r); } };
+    for (int64_t r = -(int64_t)(bf + 1); r <= 0; ++r) need_l(r);
+    {
+        size_t flat = 0; (void)flat;
+        for (const QueryH& q : vk.instance_queries) {
+            if (q.column.index >= col_lens.size()) { err = "instance query names a missing column"; return H2V_ERR_FORMAT; }
+            for (size_t j = 0; j < col_lens[q.column.index]; ++j) need_l((int64_t)j - q.rotation);
+        }
+    }
+
+    // ---------------- symbolic SHPLONK bookkeeping needs the query list; build evals first
+    std::vector<Val> advice_evals(Qa), fixed_evals(Qf), sigma_evals(P);
+    for (size_t i = 0; i < Qa; ++i) advice_evals[i] = b.load_scalar(s_adv[i]);
+    for (size_t i = 0; i < Qf; ++i) fixed_evals[i] = b.load_scalar(s_fix[i]);
+    for (size_t i = 0; i < P; ++i) sigma_evals[i] = b.load_scalar(s_sigma[i]);
+    Val random_eval = b.load_scalar(s_random);
+
+    // rotation sets (shplonk.rs:58-149), symbolic in the rotation; the evaluations are filled in below
+    std::vector<SymQuery> queries;
+    auto add_query = [&](CommitRef c, int64_t rot, Val e) { queries.push_back({c, norm_rot(rot), e}); };
+    // (the eval Vals of h / instance-dependent values are patched after they exist; collect structure first)
+    for (size_t qi = 0; qi < Qa; ++qi) {
+        if (vk.advice_queries[qi].column.index >= A) { err = "advice query names a missing column"; return H2V_ERR_FORMAT; }
+        add_query({K_ADVICE, (int)vk.advice_queries[qi].column.index}, vk.advice_queries[qi].rotation, advice_evals[qi]);
+    }
+    std::vector<Val> pz(nsets), pz_next(nsets), pz_last(nsets);
+    for (size_t i = 0; i < nsets; ++i) { pz[i] = b.load_scalar(s_perm[i].eval); pz_next[i] = b.load_scalar(s_perm[i].next); if (s_perm[i].has_last) pz_last[i] = b.load_scalar(s_perm[i].last); }
+    for (size_t i = 0; i < nsets; ++i) { add_query({K_PERM_PRODUCT, (int)i}, 0, pz[i]); add_query({K_PERM_PRODUCT, (int)i}, 1, pz_next[i]); }
+    for (size_t i = nsets; i-- > 0;) { if (i + 1 == nsets) continue; add_query({K_PERM_PRODUCT, (int)i}, -(int64_t)(bf + 1), pz_last[i]); }
+    struct LV { Val product, product_next, input, input_inv, table; };
+    std::vector<LV> lk(L);
+    for (size_t i = 0; i < L; ++i) {
+        lk[i] = {b.load_scalar(s_lk[i].product), b.load_scalar(s_lk[i].product_next), b.load_scalar(s_lk[i].input), b.load_scalar(s_lk[i].input_inv), b.load_scalar(s_lk[i].table)};
+        add_query({K_LOOKUP, (int)(3 * i + 0)}, 0, lk[i].product);
+        add_query({K_LOOKUP, (int)(3 * i + 1)}, 0, lk[i].input);
+        add_query({K_LOOKUP, (int)(3 * i + 2)}, 0, lk[i].table);
+        add_query({K_LOOKUP, (int)(3 * i + 1)}, -1, lk[i].input_inv);
+        add_query({K_LOOKUP, (int)(3 * i + 0)}, 1, lk[i].product_next);
+    }
+    struct SV2 { Val product, product_next; };
+    std::vector<SV2> shv(Sh);
+    for (size_t i = 0; i < Sh; ++i) {
+        shv[i] = {b.load_scalar(s_sh[i].product), b.load_scalar(s_sh[i].product_next)};
+        add_query({K_SHUFFLE, (int)i}, 0, shv[i].product);
+        add_query({K_SHUFFLE, (int)i}, 1, shv[i].product_next);
+    }
+    for (size_t qi = 0; qi < Qf; ++qi) {
+        if (vk.fixed_queries[qi].column.index >= vk.fixed_commitments.size()) { err = "fixed query names a missing column"; return H2V_ERR_FORMAT; }
+        add_query({K_FIXED, (int)vk.fixed_queries[qi].column.index}, vk.fixed_queries[qi].rotation, fixed_evals[qi]);
+    }
+    for (size_t i = 0; i < P; ++i) add_query({K_PERM_COMMON, (int)i}, 0, sigma_evals[i]);
+    const size_t q_hmsm = queries.size();
+    add_query({K_H_MSM, 0}, 0, 0 /* patched: expected_h_eval */);
+    add_query({K_RANDOM, 0}, 0, random_eval);
+
+    struct RotSet { std::vector<int64_t> rots; std::vector<CommitRef> commits; };
+    std::vector<RotSet> rsets; std::set<int64_t> super;
+    {
+        std::vector<std::pair<CommitRef, std::set<int64_t>>> cmap;
+        for (const SymQuery& q : queries) {
+            super.insert(q.rot);
+            bool found = false;
+            for (auto& e : cmap) if (e.first == q.c) { e.second.insert(q.rot); found = true; break; }
+            if (!found) cmap.push_back({q.c, {q.rot}});
+        }
+        for (auto& e : cmap) {
+            bool found = false;
+            for (auto& r : rsets) if (std::set<int64_t>(r.rots.begin(), r.rots.end()) == e.second) { r.commits.push_back(e.first); found = true; break; }
+            if (!found) rsets.push_back({std::vector<int64_t>(e.second.begin(), e.second.end()), {e.first}});
+        }
+    }
+
+    // ---------------- batch inversion
+    std::map<int64_t, Val> point_of;  // x * omega^rot for the opening points
+    for (int64_t r : super) point_of[r] = b.mul(x, b.cst(omega_pow(r)));
+    Val z_diff_0 = b.one();
+    for (int64_t r : super) if (std::find(rsets[0].rots.begin(), rsets[0].rots.end(), r) == rsets[0].rots.end()) z_diff_0 = b.mul(b.sub(su, point_of[r]), z_diff_0);
+    std::vector<Val> inv_list = {xn_m1, x, z_diff_0};
+    for (int64_t r : l_rots) inv_list.push_back(b.sub(x, b.cst(omega_pow(r))));
+    b.batch_invert(inv_list);
+    Val xn_m1_inv = inv_list[0], x_inv = inv_list[1], z_0_diff_inverse = inv_list[2];
+    Val common = b.mul(xn_m1, b.cst(n_inv));  // (xn - 1) * barycentric_weight   (poly/domain.rs:206)
+    auto l_at = [&](int64_t r) { size_t i = l_index[norm_rot(r)]; return b.mul(b.mul(inv_list[3 + i], common), b.cst(omega_pow(l_rots[i]))); };
+
+    // ---------------- instance evaluations (lib.rs:173-218): sum_j inst[col][j] * l_{j - rot}(x)
+    std::vector<Val> instance_evals;
+    {
+        std::vector<uint32_t> col_base(col_lens.size(), 0);
+        for (size_t c = 1; c < col_lens.size(); ++c) col_base[c] = col_base[c - 1] + (uint32_t)col_lens[c - 1];
+        std::map<int64_t, Val> l_cache;
+        for (const QueryH& q : vk.instance_queries) {
+            Val acc = b.zero();
+            for (size_t j = 0; j < col_lens[q.column.index]; ++j) {
+                int64_t r = norm_rot((int64_t)j - q.rotation);
+                if (!l_cache.count(r)) l_cache[r] = l_at(r);
+                acc = b.add(acc, b.mul(b.load_inst(col_base[q.column.index] + (uint32_t)j), l_cache[r]));
+            }
+            instance_evals.push_back(acc);
+        }
+    }
+    // l_last, l_blind, l_0 (lib.rs:259-270)
+    Val l_last = l_at(-(int64_t)(bf + 1));
+    Val l_blind = b.zero();
+    for (int64_t r = -(int64_t)bf; r <= -1; ++r) l_blind = b.add(l_blind, l_at(r));
+    Val l_0 = l_at(0);
+
+    // ---------------- expressions (lib.rs:273-346)
+    const size_t Qi = vk.instance_queries.size();
+    std::map<std::pair<uint32_t, uint32_t>, Val> pow_cache;
+    int expr_err = 0;
+    auto var_at = [&](uint32_t idx) -> Val {
+        if (idx < Qa) return advice_evals[idx];
+        if (idx < Qa + Qf) return fixed_evals[idx - Qa];
+        if (idx < Qa + Qf + Qi) return instance_evals[idx - Qa - Qf];
+        if (idx < Qa + Qf + Qi + Ch) return user_ch[idx - Qa - Qf - Qi];
+        expr_err = 1; return b.zero();  // "index out of range" panic (vk.rs:501)
+    };
+    auto eval_expr = [&](const ExprH& e) -> Val {
+        if (e.terms.empty()) { expr_err = 1; return b.zero(); }  // unwrap on empty terms (multilinear.rs:65)
+        Val sum = 0; bool first = true;
+        for (const TermH& t : e.terms) {
+            if (t.coeff_idx >= vk.coeff_vals.size()) { expr_err = 1; return b.zero(); }
+            Val prod = b.one();
+            for (const auto& f : t.factors) {
+                auto key = std::make_pair(f.first, f.second);
+                auto it = pow_cache.find(key);
+                Val pv = it != pow_cache.end() ? it->second : (pow_cache[key] = b.pow(var_at(f.first), f.second));
+                prod = b.mul(prod, pv);
+            }
+            Val term = b.mul(b.cst(vk.coeff_vals[t.coeff_idx]), prod);
+            sum = first ? term : b.add(sum, term);
+            first = false;
+        }
+        return sum;
+    };
+    std::vector<Val> exprs;
+    for (const ExprH& g : vk.gates) exprs.push_back(eval_expr(g));
+    auto column_eval = [&](const ColumnH& c) -> Val {  // get_any_query_index(column, Rotation::cur()) (vk.rs:413-455)
+        const std::vector<QueryH>& qs = c.type <= 2 ? vk.advice_queries : (c.type == COL_FIXED ? vk.fixed_queries : vk.instance_queries);
+        for (size_t i = 0; i < qs.size(); ++i)
+            if (qs[i].column.index == c.index && qs[i].column.type == c.type && qs[i].rotation == 0)
+                return c.type <= 2 ? advice_evals[i] : (c.type == COL_FIXED ? fixed_evals[i] : instance_evals[i]);
+        expr_err = 1; return b.zero();
+    };
+    Val active_rows = b.sub(b.one(), b.add(l_last, l_blind));
+    if (nsets > 0) {  // permutation.rs:189-288
+        exprs.push_back(b.mul(l_0, b.sub(b.one(), pz[0])));
+        exprs.push_back(b.mul(b.sub(b.sqr(pz[nsets - 1]), pz[nsets - 1]), l_last));
+        for (size_t i = 1; i < nsets; ++i) exprs.push_back(b.mul(b.sub(pz[i], pz_last[i - 1]), l_0));
+        Val beta_x = b.mul(beta, x);
+        for (size_t ci = 0; ci < nsets; ++ci) {
+            size_t lo = ci * chunk, hi = std::min(P, lo + chunk);
+            Val left = pz_next[ci], right = pz[ci];
+            Fr dpow = delta.pow_u32((uint32_t)(ci * chunk));
+            for (size_t j = lo; j < hi; ++j) {
+                Val v = column_eval(vk.permutation_columns[j]);
+                left = b.mul(left, b.add(b.add(v, b.mul(beta, sigma_evals[j])), gamma));
+                right = b.mul(right, b.add(b.add(v, b.mul(beta_x, b.cst(dpow))), gamma));
+                dpow = dpow * delta;
+            }
+            exprs.push_back(b.mul(b.sub(left, right), active_rows));
+        }
+    }
+    auto compress = [&](const std::vector<ExprH>& es) { Val acc = b.zero(); for (const ExprH& e : es) acc = b.add(b.mul(acc, theta), eval_expr(e)); return acc; };
+    for (size_t i = 0; i < L; ++i) {  // lookup.rs:159-230
+        const LV& e = lk[i];
+        exprs.push_back(b.mul(l_0, b.sub(b.one(), e.product)));
+        exprs.push_back(b.mul(l_last, b.sub(b.sqr(e.product), e.product)));
+        Val left = b.mul(b.mul(e.product_next, b.add(e.input, beta)), b.add(e.table, gamma));
+        Val right = b.mul(b.mul(e.product, b.add(compress(vk.lookups[i].input), beta)), b.add(compress(vk.lookups[i].table), gamma));
+        exprs.push_back(b.mul(b.sub(left, right), active_rows));
+        exprs.push_back(b.mul(l_0, b.sub(e.input, e.table)));
+        exprs.push_back(b.mul(b.mul(b.sub(e.input, e.table), b.sub(e.input, e.input_inv)), active_rows));
+    }
+    for (size_t i = 0; i < Sh; ++i) {  // shuffle.rs:148-203
+        const SV2& e = shv[i];
+        exprs.push_back(b.mul(l_0, b.sub(b.one(), e.product)));
+        exprs.push_back(b.mul(l_last, b.sub(b.sqr(e.product), e.product)));
+        Val left = b.mul(e.product_next, b.add(compress(vk.shuffles[i].shuffle), gamma));
+        Val right = b.mul(e.product, b.add(compress(vk.shuffles[i].input), gamma));
+        exprs.push_back(b.mul(b.sub(left, right), active_rows));
+    }
+    if (expr_err) { err = "the VK makes the reference panic (empty expression polynomial or out-of-range index)"; return H2V_ERR_REFERENCE_PANIC; }
+    // vanishing.rs:92-121
+    Val h_eval = b.zero();
+    for (Val v : exprs) h_eval = b.add(b.mul(h_eval, y), v);
+    Val expected_h_eval = b.mul(h_eval, xn_m1_inv);
+    queries[q_hmsm].eval = expected_h_eval;
+
+    // ---------------- SHPLONK scalar preparation (shplonk.rs:202-264)
+    auto eval_of = [&](const CommitRef& c, int64_t rot) -> Val {
+        for (const SymQuery& q : queries) if (q.c == c && q.rot == rot) return q.eval;
+        return b.zero();
+    };
+    Val mult = b.load_mult();
+    std::vector<Val> msm_scalar(np, (Val)-1);                    // per point slot
+    const size_t F = vk.fixed_commitments.size();
+    plan.n_shared = (uint32_t)(F + P + 1);
+    std::vector<Val> shared_scalar(plan.n_shared, (Val)-1);
+    plan.shared_bases.clear();
+    for (const G1A& c : vk.fixed_commitments) plan.shared_bases.push_back(c);
+    for (const G1A& c : vk.permutation_commitments) plan.shared_bases.push_back(c);
+    plan.shared_bases.push_back(params.g);
+    auto slot_of = [&](const CommitRef& c) -> std::pair<uint8_t, uint32_t> {  // (is_shared, index)
+        switch (c.kind) {
+            case K_ADVICE: return {0, advice_slot[c.idx]};
+            case K_PERM_PRODUCT: return {0, perm_slot[c.idx]};
+            case K_LOOKUP: return {0, c.idx % 3 == 0 ? lk_product_slot[c.idx / 3] : (c.idx % 3 == 1 ? lk_input_slot[c.idx / 3] : lk_table_slot[c.idx / 3])};
+            case K_SHUFFLE: return {0, sh_slot[c.idx]};
+            case K_FIXED: return {1, (uint32_t)c.idx};
+            case K_PERM_COMMON: return {1, (uint32_t)(F + c.idx)};
+            case K_RANDOM: return {0, random_slot};
+            default: return {0, 0};
+        }
+    };
+    auto assign = [&](std::pair<uint8_t, uint32_t> where, Val v) {
+        plan.right_term_order.push_back(where);
+        Val& dst = where.first ? shared_scalar[where.second] : msm_scalar[where.second];
+        dst = dst == (Val)-1 ? v : b.add(dst, v);  // a commitment appears in exactly one rotation set; the add is for safety only
+    };
+    Val z_0 = b.one();
+    for (int64_t r : rsets[0].rots) z_0 = b.mul(b.sub(su, point_of[r]), z_0);
+    Val r_outer = b.zero();
+    Val power_of_v = b.one();
+    // powers of x^-1 for the interpolation denominators
+    std::vector<Val> xinv_pow = {b.one(), x_inv};
+    for (size_t i = 0; i < rsets.size(); ++i) {
+        const RotSet& rs = rsets[i];
+        Val z_diff_i;
+        if (i == 0) z_diff_i = b.one();
+        else {
+            Val zd = b.one();
+            for (int64_t r : super) if (std::find(rs.rots.begin(), rs.rots.end(), r) == rs.rots.end()) zd = b.mul(b.sub(su, point_of[r]), zd);
+            z_diff_i = b.mul(zd, z_0_diff_inverse);
+        }
+        // Lagrange weights at u over this set's points: W_k = prod_{m != k}(u - p_m) / prod_{m != k}(p_k - p_m),
+        // p_k - p_m = x (omega^rk - omega^rm): the omega part is a per-VK constant, the x part one shared inverse.
+        size_t s = rs.rots.size();
+        std::vector<Val> W(s);
+        if (s > 1) {
+            while (xinv_pow.size() < s) xinv_pow.push_back(b.mul(xinv_pow.back(), x_inv));
+            for (size_t k2 = 0; k2 < s; ++k2) {
+                Fr cden = Fr::one();
+                Val num = b.one();
+                for (size_t m = 0; m < s; ++m) {
+                    if (m == k2) continue;
+                    cden = cden * (omega_pow(rs.rots[k2]) - omega_pow(rs.rots[m]));
+                    num = b.mul(num, b.sub(su, point_of[rs.rots[m]]));
+                }
+                W[k2] = b.mul(b.mul(num, xinv_pow[s - 1]), b.cst(cden.inv()));
+            }
+        }
+        Val set_weight = b.mul(power_of_v, z_diff_i);
+        Val r_inner = b.zero();
+        Val power_of_y = b.one();
+        for (size_t j = 0; j < rs.commits.size(); ++j) {
+            const CommitRef& c = rs.commits[j];
+            Val r_u;  // r_ij(u)
+            if (s == 1) r_u = eval_of(c, rs.rots[0]);
+            else { r_u = b.zero(); for (size_t k2 = 0; k2 < s; ++k2) r_u = b.add(r_u, b.mul(eval_of(c, rs.rots[k2]), W[k2])); }
+            r_inner = b.add(r_inner, b.mul(power_of_y, r_u));
+            Val term_scalar = b.mul(power_of_y, set_weight);
+            if (c.kind == K_H_MSM) {
+                // nested MSM: bases h_{H-1} .. h_0 with scalars xn^{H-1} .. 1 (vanishing.rs:102-112)
+                std::vector<Val> xnp(H); if (H) xnp[0] = b.one();
+                for (size_t t = 1; t < H; ++t) xnp[t] = b.mul(xnp[t - 1], xn);
+                for (size_t t = H; t-- > 0;) assign({0, h_slot[t]}, b.mul(term_scalar, xnp[t]));
+            } else {
+                assign(slot_of(c), term_scalar);
+            }
+            power_of_y = b.mul(sy, power_of_y);
+        }
+        r_outer = b.add(r_outer, b.mul(b.mul(power_of_v, r_inner), z_diff_i));
+        power_of_v = b.mul(sv, power_of_v);
+    }
+    assign({1, (uint32_t)(F + P)}, b.neg(r_outer));
+    assign({0, plan.slot_h1}, b.neg(z_0));
+    assign({0, plan.slot_h2}, su);
+    // stores, scaled by the proof's batch multiplier (kzg/strategy.rs:129, msm.rs:173-176)
+    for (uint32_t s2 = 0; s2 < np; ++s2) b.store_msm(msm_scalar[s2] == (Val)-1 ? b.zero() : b.mul(msm_scalar[s2], mult), s2);
+    for (uint32_t j = 0; j < plan.n_shared; ++j) b.store_shared(shared_scalar[j] == (Val)-1 ? b.zero() : b.mul(shared_scalar[j], mult), j);
+    b.store_left(mult);  // left channel: (1, h2) per proof (shplonk.rs:262)
+
+    b.emit(plan.code, plan.n_slots);
+    plan.consts = b.consts;
+    // LOAD_CHAL immediates already refer to squeeze order
+    return 0;
+}
+
+// =============================================================================== device upload
+template <class T> static int upload_vec(const std::vector<T>& v, T*& d) {
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    H2V_HIP_CHECK(hipMalloc(&d, bytes));
+    if (!v.empty()) H2V_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+int PlanDevice::upload() {
+    int rc;
+    if ((rc = upload_vec(host.code, code))) return rc;
+    if ((rc = upload_vec(host.consts, consts))) return rc;
+    if ((rc = upload_vec(host.stream, stream))) return rc;
+    if ((rc = upload_vec(host.squeeze_at, squeeze_at))) return rc;
+    if ((rc = upload_vec(host.point_offsets, point_offsets))) return rc;
+    if ((rc = upload_vec(host.scalar_offsets, scalar_offsets))) return rc;
+    if ((rc = upload_vec(host.shared_bases, shared_bases))) return rc;
+    return 0;
+}
+void PlanDevice::release() {
+    hipFree(code); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases);
+    code = nullptr; consts = nullptr; stream = nullptr; squeeze_at = nullptr; point_offsets = nullptr; scalar_offsets = nullptr; shared_bases = nullptr;
+}
+
+int ctx_load_vk(h2v_ctx* ctx, const uint8_t* vk, size_t vk_len, int vk_format) {
+    VkDevice* v = new VkDevice();
+    std::string err;
+    if (!vk_from_bytes(vk, vk_len, vk_format, v->vk, err)) { set_last_error("VerifyingKey: " + err); delete v; return H2V_ERR_FORMAT; }
+    if (v->vk.k != ctx->params.k) { set_last_error("VerifyingKey: k differs from ParamsKZG.k"); delete v; return H2V_ERR_BAD_ARGUMENT; }
+    ctx->vk = v;
+    return 0;
+}
+void ctx_release_vk(h2v_ctx* ctx) {
+    if (!ctx->vk) return;
+    for (auto& kv : ctx->vk->plans) { kv.second->release(); delete kv.second; }
+    delete ctx->vk;
+    ctx->vk = nullptr;
+}
+int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice** out) {
+    if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
+    std::lock_guard<std::mutex> lock(ctx->vk->mu);
+    auto it = ctx->vk->plans.find(col_lens);
+    if (it != ctx->vk->plans.end()) { *out = it->second; return 0; }
+    PlanDevice* pd = new PlanDevice();
+    std::string err;
+    int rc = compile_plan(ctx->vk->vk, ctx->params, col_lens, pd->host, err);
+    if (rc) { set_last_error("plan: " + err); delete pd; return rc; }
+    H2V_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = pd->upload();
+    if (rc) { pd->release(); delete pd; return rc; }
+    ctx->vk->plans[col_lens] = pd;
+    *out = pd;
+    return 0;
+}
+
+}  // namespace h2v

@@ -138,7 +138,8 @@ class Context:
                 raise ValueError("all proofs of a batch must share one instance shape")
             lens = l
             flats.append(f)
-        lens = lens or []
+        if lens is None:  # empty batch: the column count comes from the VK
+            lens = [0] * self.proof_shape()["n_instance_columns"]
         ia = PA(*flats) if n else PA()
         cl = (ctypes.c_size_t * max(len(lens), 1))(*lens)
         rb = None
@@ -161,7 +162,8 @@ class Context:
             f, l = _flatten_instances(inst)
             lens = l
             flats.append(f)
-        lens = lens or []
+        if lens is None:
+            lens = [0] * self.proof_shape()["n_instance_columns"]
         ia = PA(*flats) if n else PA()
         cl = (ctypes.c_size_t * max(len(lens), 1))(*lens)
         st = (ctypes.c_int * max(n, 1))()

@@ -1,0 +1,138 @@
+"""Test inputs: VK / params / proofs produced by the oracle's test-only keygen + prover
+(oracle/prover.cpp).  The reference ships no proof bytes, so every proof used by the
+tests is generated here, deterministically from seeds."""
+import ctypes
+import os
+
+import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRS_PATH = os.path.join(ROOT, "tests", "golden", "kzg_bn254_8.srs")
+RAW = 1  # SerdeFormat::RawBytes
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+def le32(x):
+    return int(x).to_bytes(32, "little")
+
+
+class Setup:
+    def __init__(self, L, handle, ninst_cols):
+        self.L, self.h, self.ninst_cols = L, handle, ninst_cols
+        buf = ctypes.create_string_buffer(1 << 22)
+        n = L.h2o_setup_vk(handle, RAW, buf, len(buf))
+        self.vk = buf.raw[:n]
+        n = L.h2o_setup_params(handle, RAW, buf, len(buf))
+        self.params = buf.raw[:n]
+
+    def free(self):
+        if self.h:
+            self.L.h2o_setup_free(self.h)
+            self.h = None
+
+
+def setup_vector_mul(k=8, n_mul=10, use_reference_srs=False, s_seed=42):
+    L = oracle_lib.load()
+    srs = open(SRS_PATH, "rb").read() if use_reference_srs else None
+    h = L.h2o_setup_vector_mul(k, n_mul, srs, len(srs) if srs else 0, s_seed)
+    assert h
+    s = Setup(L, h, 1)
+    s.n_mul = n_mul
+    return s
+
+
+def prove_vector_mul(s, a, b, rng_seed=7):
+    """a, b: lists of ints (len n_mul) -> (proof bytes, instances [[c...]])"""
+    ab = b"".join(le32(x) for x in a)
+    bb = b"".join(le32(x) for x in b)
+    buf = ctypes.create_string_buffer(1 << 16)
+    inst = ctypes.create_string_buffer(32 * s.n_mul)
+    n = s.L.h2o_prove_vector_mul(s.h, ab, bb, rng_seed, buf, len(buf), inst)
+    assert n > 0
+    return buf.raw[:n], [[inst.raw[32 * i:32 * i + 32] for i in range(s.n_mul)]]
+
+
+def prove_vector_mul_batch(s, count, seed=1, threads=8, proof_len=1024):
+    proofs = ctypes.create_string_buffer(count * proof_len)
+    inst = ctypes.create_string_buffer(count * 32 * s.n_mul)
+    got = s.L.h2o_prove_vector_mul_batch(s.h, count, seed, threads, proofs, proof_len, inst)
+    assert got == count
+    P = [proofs.raw[i * proof_len:(i + 1) * proof_len] for i in range(count)]
+    I = [[[inst.raw[32 * (i * s.n_mul + j):32 * (i * s.n_mul + j + 1)] for j in range(s.n_mul)]] for i in range(count)]
+    return P, I
+
+
+def setup_shuffle(k=8, W=4, H=32, s_seed=43):
+    L = oracle_lib.load()
+    h = L.h2o_setup_shuffle(k, W, H, None, 0, s_seed)
+    assert h
+    return Setup(L, h, 0)
+
+
+def prove_shuffle(s, data_seed=5, break_it=False, rng_seed=9):
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = s.L.h2o_prove_shuffle(s.h, data_seed, 1 if break_it else 0, rng_seed, buf, len(buf))
+    assert n > 0
+    return buf.raw[:n], []
+
+
+def setup_wide(k=8, A=8, F=5, L_=1, Sh=1, deg=3, seed=11, s_seed=44):
+    L = oracle_lib.load()
+    h = L.h2o_setup_wide(k, A, F, L_, Sh, deg, seed, None, 0, s_seed)
+    assert h
+    return Setup(L, h, 1)
+
+
+def prove_wide(s, witness_seed=3, tamper=False, rng_seed=13):
+    buf = ctypes.create_string_buffer(1 << 20)
+    inst = ctypes.create_string_buffer(32 * 8)
+    n = s.L.h2o_prove_wide(s.h, witness_seed, 1 if tamper else 0, rng_seed, buf, len(buf), inst)
+    assert n > 0
+    return buf.raw[:n], [[inst.raw[32 * i:32 * i + 32] for i in range(8)]]
+
+
+# ---- oracle-side verification helpers (the checker)
+def _flat(instances):
+    flat = b"".join(b"".join(col) for col in instances)
+    lens = [len(col) for col in instances]
+    return flat, (ctypes.c_size_t * max(len(lens), 1))(*lens), len(lens)
+
+
+def oracle_verify_single(s, proof, instances):
+    f, cl, nc = _flat(instances)
+    return s.L.h2o_verify_single(s.params, len(s.params), RAW, s.vk, len(s.vk), RAW, f, cl, nc, proof, len(proof))
+
+
+def oracle_guard(s, proof, instances, cap=4096):
+    f, cl, nc = _flat(instances)
+    rs, rb = ctypes.create_string_buffer(32 * cap), ctypes.create_string_buffer(64 * cap)
+    ls, lb = ctypes.create_string_buffer(32 * 16), ctypes.create_string_buffer(64 * 16)
+    ch = ctypes.create_string_buffer(32 * 64)
+    nr, nl, ncz = ctypes.c_size_t(cap), ctypes.c_size_t(16), ctypes.c_size_t(64)
+    rc = s.L.h2o_guard_msm(s.params, len(s.params), RAW, s.vk, len(s.vk), RAW, f, cl, nc, proof, len(proof), rs, rb, ctypes.byref(nr), ls, lb, ctypes.byref(nl), ch, ctypes.byref(ncz))
+    if rc != 0:
+        return rc, None
+    sp = lambda buf, sz, n: [buf.raw[sz * i:sz * (i + 1)] for i in range(n)]
+    return 0, dict(right_scalars=sp(rs, 32, nr.value), right_bases=sp(rb, 64, nr.value), left_scalars=sp(ls, 32, nl.value), left_bases=sp(lb, 64, nl.value),
+                   challenges=sp(ch, 32, ncz.value))
+
+
+def oracle_verify_batch(s, proofs, instances, rand):
+    n = len(proofs)
+    plen = len(proofs[0]) if n else 0
+    assert all(len(p) == plen for p in proofs)
+    pf = b"".join(proofs)
+    flat = b""
+    cl, nc = (ctypes.c_size_t * 1)(0), 0
+    for inst in instances:
+        f, cl, nc = _flat(inst)
+        flat += f
+    if n == 0:
+        nc = s.ninst_cols
+    rb = b"".join(le32(r) if not isinstance(r, (bytes, bytearray)) else r for r in rand)
+    st = (ctypes.c_int * max(n, 1))()
+    ok = ctypes.c_int(0)
+    left, right = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    rc = s.L.h2o_verify_batch(s.params, len(s.params), RAW, s.vk, len(s.vk), RAW, n, pf, plen, flat, cl, nc, rb, st, ctypes.byref(ok), left, right)
+    assert rc == 0, rc
+    return bool(ok.value), list(st)[:n], left.raw, right.raw
