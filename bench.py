@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: proofs verified / second (BN254, k = 14) on N MI355X of one node.
+
+One "step" = one pass of the whole hot path (point decompression -> Blake2b transcript -> Fr program
+-> shared-base fold -> pooled MSMs -> one pairing) over one batch of `--batch` proofs PER GPU that is
+already resident in HBM.  N > 1: every rank verifies its own shard, the 2 accumulator points per rank
+are all-gathered over RCCL and folded, and a single pairing closes the whole N x batch step (weak scaling).
+Steps are pipelined over `--depth` batch objects (one HIP stream each) because the tail of a batch —
+window Horner, the pairing — is a single wave; all K timed steps start and finish inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the MSM stage (the kernel BASELINE.json names):
+achieved = 96 B x terms / mean MSM-stage time measured with HIP events on the batch's own stream.
+`cpu_baseline` = the CPU oracle (a port of the reference algorithm, single thread like the reference)
+timed on a bounded sample of the same proofs on this host.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+K_CIRCUIT = 14
+N_PUBLIC = 8
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def load_or_make_proofs(count, k, log):
+    """`count` distinct proofs of the vector_mul circuit, cached on disk."""
+    import circuits
+    cache = os.path.join(ROOT, ".bench_cache")
+    os.makedirs(cache, exist_ok=True)
+    tag = f"vm_k{k}_pub{N_PUBLIC}_n{count}"
+    paths = {x: os.path.join(cache, f"{tag}.{x}") for x in ("proofs", "inst", "vk", "params")}
+    if all(os.path.exists(p) for p in paths.values()):
+        d = {x: open(p, "rb").read() for x, p in paths.items()}
+        if len(d["proofs"]) == count * 1024 and len(d["inst"]) == count * 32 * N_PUBLIC:
+            return d
+    t = time.time()
+    s = circuits.setup_vector_mul(k, N_PUBLIC, s_seed=0x48325630)  # known-s test SRS, s from seed "H2V0"
+    threads = min(32, os.cpu_count() or 1)
+    P, I = circuits.prove_vector_mul_batch(s, count, seed=0x48325630, threads=threads)
+    d = dict(proofs=b"".join(P), inst=b"".join(b"".join(col) for inst in I for col in inst), vk=s.vk, params=s.params)
+    s.free()
+    for x, p in paths.items():
+        with open(p, "wb") as f:
+            f.write(d[x])
+    log(f"generated {count} proofs (k={k}) with {threads} threads in {time.time() - t:.1f}s")
+    return d
+
+
+def cpu_baseline(d, sample, log):
+    """CPU oracle, AccumulatorStrategy semantics (N x verify_proof + one pairing), one thread."""
+    import oracle_lib
+    L = oracle_lib.load()
+    n = sample
+    rand = b"".join((i * 0x9e3779b97f4a7c15 + 12345).to_bytes(32, "little") for i in range(1, n + 1))
+    st = (ctypes.c_int * n)()
+    ok = ctypes.c_int(0)
+    left, right = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    cl = (ctypes.c_size_t * 1)(N_PUBLIC)
+    t0 = time.perf_counter()
+    rc = L.h2o_verify_batch(d["params"], len(d["params"]), 1, d["vk"], len(d["vk"]), 1, n, d["proofs"], 1024, d["inst"], cl, 1, rand, st, ctypes.byref(ok), left, right)
+    dt = time.perf_counter() - t0
+    assert rc == 0 and ok.value == 1
+    return dict(value=n / dt, unit="proofs/s", cores=1, kind="port",
+                sample=f"{n} of the bench proofs, AccumulatorStrategy (N x verify_proof + 1 pairing), oracle/ C++ port, 1 thread, {dt:.2f}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
+    ap.add_argument("--depth", type=int, default=8, help="batches in flight per GPU")
+    ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    log = (lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if rank == 0 else (lambda m: None)
+
+    import torch
+    import torch.distributed as dist
+    import halo2_verifier_amd as h2v
+    from halo2_verifier_amd import distributed as h2d
+
+    if not torch.cuda.is_available() or h2v.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # inputs: rank 0 generates (or loads) the proofs, the others wait and read the cache
+    if rank == 0:
+        d = load_or_make_proofs(args.distinct, K_CIRCUIT, log)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        d = load_or_make_proofs(args.distinct, K_CIRCUIT, log)
+
+    B = args.batch
+    reps = (B + args.distinct - 1) // args.distinct
+    proofs_flat = (d["proofs"] * reps)[: B * 1024]
+    inst_flat = (d["inst"] * reps)[: B * 32 * N_PUBLIC]
+    total = B * world
+    # one seeded stream of Fr::random draws for the whole (N x batch) step, indexed by global proof id
+    rand_all = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567) % (1 << 250)).to_bytes(32, "little") for i in range(1, total + 1))
+    lo, hi = h2d.shard_bounds(total, world, rank)
+    tail = h2d.tail_for_shard(rand_all, lo)
+
+    ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes), device=local_rank)
+    shape = ctx.proof_shape()
+    depth = max(1, min(args.depth, args.steps))
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)]
+    batches = []
+    for s in streams:
+        b = h2v.Batch(ctx, B, N_PUBLIC, stream=s.cuda_stream)
+        b.upload(proofs_flat, 1024, inst_flat, [N_PUBLIC], tail)   # resident in HBM before the timed region
+        b.set_profiling(True)
+        batches.append(b)
+    acc_local = [torch.empty(h2d.ACC_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(depth)]
+    gathered = [None] * depth
+    in_flight = [False] * depth
+    stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
+    stage_cnt = 0
+    results = []
+
+    def retire(i, timed):
+        nonlocal stage_cnt
+        ok, st, left, right = batches[i].finish()
+        in_flight[i] = False
+        if not ok or any(st):
+            raise SystemExit(f"verification failed inside the benchmark: ok={ok}")
+        if timed:
+            for k2, v in batches[i].timings_ms().items():
+                stage_sum[k2] += v
+            stage_cnt += 1
+        results.append((left, right))
+
+    def submit(i):
+        b = batches[i]
+        if world == 1:
+            b.launch(with_pairing=True)
+        else:
+            with torch.cuda.stream(streams[i]):
+                b.launch(with_pairing=False)
+                b.export_accumulators(acc_local[i].data_ptr())
+                gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of 192 B per rank
+                b.fold_check_enqueue(gathered[i].data_ptr(), world)          # fold + the ONE pairing for the whole step
+        in_flight[i] = True
+
+    def run(nsteps, timed):
+        for step in range(nsteps):
+            i = step % depth
+            if in_flight[i]:
+                retire(i, timed)
+            submit(i)
+        for i in range(depth):
+            if in_flight[i]:
+                retire(i, timed)
+
+    run(args.warmup, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        stages = {k2: v / max(stage_cnt, 1) for k2, v in stage_sum.items()}
+        n_local = hi - lo
+        # terms of one launch: every point slot of every local proof (right channel) + the VK-wide bases folded
+        # over the batch (fixed + permutation commitments + g) + one h2 term per proof (left channel)
+        n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
+        terms_total = n_local * shape["n_points"] + n_shared + n_local
+        msm_ms = stages["msm"]
+        achieved = (96.0 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
+        out = {
+            "metric": "proofs verified/sec (BN254, k=14)",
+            "value": total * args.steps / dt,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (254-bit prime-field integers)",
+            "data": "synthetic",
+            "config": {"workload": f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
+                                   f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step), {args.distinct} distinct proofs",
+                       "proofs_per_gpu_per_step": B, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "MSM stage (msm_count/scan/scatter/bucket/window/final, both channels)", "terms_per_launch": terms_total,
+                         "mean_stage_ms": msm_ms},
+            "stages_ms": stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline({**d, "proofs": (d["proofs"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 1024],
+                                                "inst": (d["inst"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 32 * N_PUBLIC]},
+                                               args.cpu_sample, log)
+        print(json.dumps(out), flush=True)
+    for b in batches:
+        b.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,9 @@ SIGNATURES = {
     "h2v_batch_finish": (c_int, [c_vp, c_intp, c_intp, c_u8p, c_u8p]),
     "h2v_batch_accumulators": (c_int, [c_vp, ctypes.POINTER(c_vp), c_szp]),
     "h2v_batch_stream": (c_vp, [c_vp]),
+    "h2v_batch_set_stream": (c_int, [c_vp, c_vp]),
+    "h2v_batch_export_accumulators": (c_int, [c_vp, c_vp]),
+    "h2v_batch_fold_check_enqueue": (c_int, [c_vp, c_vp, c_sz]),
     "h2v_fold_check": (c_int, [c_vp, c_vp, c_sz, c_intp, c_u8p, c_u8p]),
     "h2v_batch_timings": (c_int, [c_vp, ctypes.POINTER(ctypes.c_float), c_int]),
     "h2v_batch_set_profiling": (c_int, [c_vp, c_int]),

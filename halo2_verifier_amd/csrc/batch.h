@@ -44,6 +44,7 @@ int msm_enqueue_strided(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scala
 struct h2v_batch {
     h2v_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     size_t max_proofs = 0, max_inst = 0;
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
     uint32_t n = 0, n_tail = 0;

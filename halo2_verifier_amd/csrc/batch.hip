@@ -272,7 +272,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     hipFree(b->out_bytes); hipFree(b->out_ident);
     b->ws_right.release(); b->ws_left.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
-    if (b->stream) hipStreamDestroy(b->stream);
+    if (b->stream && b->owns_stream) hipStreamDestroy(b->stream);
     delete b;
 }
 
@@ -291,6 +291,30 @@ int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes) {
     return 0;
 }
 void* h2v_batch_stream(h2v_batch* b) { return b ? (void*)b->stream : nullptr; }
+int h2v_batch_set_stream(h2v_batch* b, void* hip_stream) {
+    if (!b) return H2V_ERR_BAD_ARGUMENT;
+    hipSetDevice(b->ctx->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->owns_stream && b->stream) hipStreamDestroy(b->stream);
+    b->stream = (hipStream_t)hip_stream; b->owns_stream = false;
+    return 0;
+}
+int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst) {
+    if (!b || !b->launched || !device_dst) { set_last_error("h2v_batch_export_accumulators: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
+    H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
+    H2V_HIP_CHECK(hipMemcpyAsync(device_dst, b->acc, 2 * sizeof(G1J), hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+}
+int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts) {
+    if (!b || !b->launched || !device_accumulators || !n_parts) { set_last_error("h2v_batch_fold_check_enqueue: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
+    H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
+    int rc;
+    if ((rc = fold_pairs_enqueue(b->stream, (const G1J*)device_accumulators, (uint32_t)n_parts, b->acc))) return rc;
+    if ((rc = pairing_check_enqueue(b->stream, b->ctx->pairing, b->acc, 1, b->ok))) return rc;
+    if ((rc = point_to_bytes_enqueue(b->stream, b->acc, b->out_bytes, b->out_ident, 2))) return rc;
+    b->with_pairing = true;
+    return 0;
+}
 int h2v_batch_set_profiling(h2v_batch* b, int enabled) { if (!b) return H2V_ERR_BAD_ARGUMENT; b->profiling = enabled != 0; return 0; }
 int h2v_batch_timings(h2v_batch* b, float* ms, int cap) {
     if (!b || !ms) return H2V_ERR_BAD_ARGUMENT;

@@ -1,0 +1,40 @@
+"""Sharded verification of one batch across the GPUs of a node (one process per GPU).
+
+The reference has no communication layer.  Proofs are independent until the final
+pairing, so the batch is cut into contiguous shards; every rank runs the whole per-proof pipeline
+and its two pooled MSMs, and the only exchange is an all-gather of 2 G1 points (2 x 96 bytes) per
+rank — RCCL has no user-defined reduction, and a group addition is not a numeric sum — followed
+by a 2(N-1)-addition fold and ONE pairing (DualMSM::add_msm + check, poly/kzg/msm.rs:178-203).
+
+Multipliers: proof i of the whole batch is scaled by the product of the Fr::random draws of all
+later proofs (kzg/strategy.rs:129, msm.rs:173-176), indexed globally, so the result does not
+depend on the number of ranks.
+"""
+
+
+def shard_bounds(total: int, world_size: int, rank: int):
+    """Contiguous shard [lo, hi) of `total` proofs for `rank`."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+ACC_BYTES = 192  # 2 x Jacobian G1 (3 x 32 B Montgomery limbs)
+
+
+def gather_accumulators(local_acc, world_size, group=None):
+    """all_gather of the per-rank accumulator bytes (torch uint8 tensor of ACC_BYTES) -> tensor [world_size * ACC_BYTES].
+    Works with the nccl (= RCCL) backend on GPU tensors and with gloo on CPU tensors (tests)."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty(world_size * ACC_BYTES, dtype=torch.uint8, device=local_acc.device)
+    if world_size == 1:
+        out.copy_(local_acc)
+        return out
+    dist.all_gather_into_tensor(out, local_acc, group=group)
+    return out
+
+
+def tail_for_shard(rand_all: bytes, lo: int):
+    """The draws this shard needs: those of proofs [lo, total)."""
+    return rand_all[32 * lo:]

@@ -240,3 +240,71 @@ def verify_batch(params, vk, proofs, instances, rand=None, device=0):
         return ctx.verify_batch(proofs, instances, rand)
     finally:
         ctx.close()
+
+
+class Batch:
+    """Staged, device-resident batch (h2v_batch): upload once, launch asynchronously on its stream, finish later.
+    Several batches may be in flight on one Context (one HIP stream each)."""
+
+    STAGES = ("decompress", "transcript", "fr_program", "fold", "msm", "pairing")
+
+    def __init__(self, ctx: Context, max_proofs: int, max_instance_values: int = 0, stream=None):
+        self.ctx, self._lib = ctx, ctx._lib
+        self._h = ctypes.c_void_p()
+        check(self._lib.h2v_batch_create(ctx._h, max_proofs, max_instance_values, ctypes.byref(self._h)))
+        self.max_proofs = max_proofs
+        self.n = 0
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self._h:
+            self._lib.h2v_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int):
+        check(self._lib.h2v_batch_set_stream(self._h, ctypes.c_void_p(hip_stream)))
+
+    @property
+    def stream(self) -> int:
+        return self._lib.h2v_batch_stream(self._h) or 0
+
+    def upload(self, proofs_flat: bytes, proof_len: int, instances_flat: bytes, col_lens, rand_tail=None):
+        """proofs_flat: n * proof_len bytes; instances_flat: n * sum(col_lens) * 32 bytes;
+        rand_tail: bytes of the Fr::random draws of proofs [first, total) of the whole batch (>= n scalars) or None."""
+        n = len(proofs_flat) // proof_len if proof_len else 0
+        cl = (ctypes.c_size_t * max(len(col_lens), 1))(*col_lens)
+        nt = len(rand_tail) // 32 if rand_tail is not None else 0
+        check(self._lib.h2v_batch_upload(self._h, n, proofs_flat, proof_len, instances_flat, len(col_lens), cl, rand_tail, nt))
+        self.n = n
+
+    def launch(self, with_pairing=True):
+        check(self._lib.h2v_batch_launch(self._h, 1 if with_pairing else 0))
+
+    def export_accumulators(self, device_dst: int):
+        check(self._lib.h2v_batch_export_accumulators(self._h, ctypes.c_void_p(device_dst)))
+
+    def fold_check_enqueue(self, device_accumulators: int, n_parts: int):
+        check(self._lib.h2v_batch_fold_check_enqueue(self._h, ctypes.c_void_p(device_accumulators), n_parts))
+
+    def finish(self):
+        """-> (batch_ok, statuses, left_xy, right_xy)"""
+        st = (ctypes.c_int * max(self.n, 1))()
+        ok = ctypes.c_int(0)
+        left, right = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        check(self._lib.h2v_batch_finish(self._h, st, ctypes.byref(ok), left, right))
+        return bool(ok.value), list(st)[:self.n], left.raw, right.raw
+
+    def set_profiling(self, on=True):
+        check(self._lib.h2v_batch_set_profiling(self._h, 1 if on else 0))
+
+    def timings_ms(self):
+        arr = (ctypes.c_float * 6)()
+        k = self._lib.h2v_batch_timings(self._h, arr, 6)
+        return dict(zip(self.STAGES, list(arr)[:k]))

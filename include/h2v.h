@@ -139,6 +139,15 @@ int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes);
 /* The HIP stream (hipStream_t) the batch runs on, for event timing and stream-ordered interop. */
 void* h2v_batch_stream(h2v_batch* b);
+/* Run the batch on a caller-owned stream (e.g. a torch.cuda.Stream's cuda_stream) instead of its own,
+ * so that collectives issued by the caller on that stream are ordered with the batch's kernels without
+ * host synchronisation.  The caller keeps the stream alive while the batch uses it. */
+int h2v_batch_set_stream(h2v_batch* b, void* hip_stream);
+/* Stream-ordered copy of the two accumulator points (2 x 96 bytes) into caller device memory. */
+int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst);
+/* Stream-ordered version of h2v_fold_check on the batch's stream: fold n_parts gathered accumulator
+ * pairs and enqueue the single pairing; the result is fetched by h2v_batch_finish (batch_ok, left, right). */
+int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts);
 /* Fold n_parts accumulator pairs (as produced by h2v_batch_accumulators, contiguous in device
  * memory) with G1 additions and run the single pairing check.
  *   replaces: DualMSM::add_msm + check across shards (poly/kzg/msm.rs:178-203). */

@@ -1,0 +1,82 @@
+"""The N > 1 path on CPU: world_size-2 gloo run of the sharding logic in halo2_verifier_amd.distributed.
+
+What is exercised: shard_bounds / tail_for_shard / gather_accumulators (the same all_gather_into_tensor call the
+GPU path issues over RCCL), and the algebra that makes the sharded result independent of the number of ranks:
+proof i is scaled by the product of the draws of ALL later proofs of the whole batch (kzg/strategy.rs:129,
+msm.rs:173-176), so a shard's accumulator computed from its own draws only needs the product of the later
+shards' draws — which is exactly what uploading the draw tail [lo, total) to h2v_batch_upload gives the GPU.
+The per-shard group arithmetic is done by the CPU oracle here (there is no GPU in this container); the GPU
+counterpart is tests/test_gpu_sharded.py."""
+import os
+import random
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits
+    import oracle_lib
+    from halo2_verifier_amd import distributed as h2d
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = oracle_lib.load()
+    s = circuits.setup_vector_mul(8, 10)
+    P, I = circuits.prove_vector_mul_batch(s, total, seed=5, threads=2)
+    rnd = random.Random(2024)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(total)]
+    rand_all = b"".join(r.to_bytes(32, "little") for r in rand)
+    lo, hi = h2d.shard_bounds(total, world, rank)
+    tail = h2d.tail_for_shard(rand_all, lo)
+    assert len(tail) == 32 * (total - lo)
+    # shard accumulator with its own draws, then scaled by the product of the later shards' draws (the tail beyond hi)
+    ok, st, left, right = circuits.oracle_verify_batch(s, P[lo:hi], I[lo:hi], rand[lo:hi])
+    T = 1
+    for j in range(hi, total):
+        T = T * rand[j] % R_MOD
+    left = oracle_lib.g1_msm(L, [T], [left]); right = oracle_lib.g1_msm(L, [T], [right])
+    local = torch.zeros(h2d.ACC_BYTES, dtype=torch.uint8)
+    local[:128] = torch.tensor(list(left + right), dtype=torch.uint8)
+    gathered = h2d.gather_accumulators(local, world)
+    parts = [bytes(gathered[i * h2d.ACC_BYTES:i * h2d.ACC_BYTES + 128].tolist()) for i in range(world)]
+    fl = oracle_lib.g1_msm(L, [1] * world, [p[:64] for p in parts])
+    fr = oracle_lib.g1_msm(L, [1] * world, [p[64:] for p in parts])
+    if rank == 0:
+        full = circuits.oracle_verify_batch(s, P, I, rand)
+        q.put((fl == full[2], fr == full[3], full[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [5, 8])
+def test_two_rank_sharding_matches_unsharded(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(300)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) == (True, True, True)
+
+
+def test_shard_bounds_cover_everything():
+    from halo2_verifier_amd.distributed import shard_bounds
+    for total in (0, 1, 7, 8, 1024, 65536):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
