@@ -59,7 +59,7 @@ int h2v_msm_g1(h2v_ctx* ctx, const uint8_t* scalars32, const uint8_t* bases64, s
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     uint32_t nn = (uint32_t)n;
-    if (nn > ctx->msm_ws.cap_terms) { int rc = ctx->msm_ws.alloc(nn < 1024 ? 1024 : nn); if (rc) return rc; }
+    if (nn > ctx->msm_ws.cap_terms) { int rc = ctx->msm_ws.alloc(nn < 1024 ? 1024 : nn, 1); if (rc) return rc; }
     uint8_t *d_sb = nullptr, *d_bb = nullptr, *d_out = nullptr; uint32_t *d_s = nullptr, *d_flags = nullptr; G1A* d_b = nullptr; G1J* d_res = nullptr;
     size_t n1 = n ? n : 1;
     H2V_HIP_CHECK(hipMalloc(&d_sb, 32 * n1)); H2V_HIP_CHECK(hipMalloc(&d_bb, 64 * n1));

@@ -35,10 +35,6 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t* d_msm_scal);
 int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared,
                        uint32_t slot_h2, G1J* d_pairs);
-// strided MSM (msm.hip): term i reads scalars[i * scalar_stride_words ..+8) and bases[i * base_stride]
-int msm_enqueue_strided(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, uint32_t scalar_stride_words, const G1A* d_bases, uint32_t base_stride,
-                        uint32_t n, G1J* d_out);
-
 }  // namespace h2v
 
 struct h2v_batch {
@@ -58,7 +54,7 @@ struct h2v_batch {
     h2v::G1J* pairs = nullptr;    // per-proof channels (SingleStrategy)
     uint32_t* ok = nullptr;       // [max_proofs] (index 0 for the batch check)
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
-    h2v::MsmWorkspace ws_right, ws_left;
+    h2v::MsmWorkspace ws;
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
     uint32_t stream_words = 0;
     // profiling

@@ -42,8 +42,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->ok, N))) return rc;
     if ((rc = dev_alloc(b->out_bytes, 128))) return rc;
     if ((rc = dev_alloc(b->out_ident, 2))) return rc;
-    if ((rc = b->ws_right.alloc((uint32_t)(N * pl.n_points + pl.n_shared)))) return rc;
-    if ((rc = b->ws_left.alloc((uint32_t)N))) return rc;
+    if ((rc = b->ws.alloc((uint32_t)(N * pl.n_points + pl.n_shared + N), 2))) return rc;
     b->cap_plan_sig = sig;
     return 0;
 }
@@ -140,8 +139,12 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
     if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, b->msm_scal))) return rc; }
     mark();
     uint32_t terms = n ? n * pl.n_points + pl.n_shared : 0;
-    if ((rc = msm_enqueue_strided(s, b->ws_right, b->msm_scal, 8, b->pts, 1, terms, b->acc + 1))) return rc;
-    if ((rc = msm_enqueue_strided(s, b->ws_left, b->left_scal, 8, b->pts + pl.slot_h2, pl.n_points, n, b->acc + 0))) return rc;
+    {   // both channels in one set of launches: [0] left = sum_p m_p * h2_p, [1] right = pooled Guard terms + folded VK-wide bases
+        MsmProblems pr; pr.count = 2;
+        pr.p[0] = MsmProblem{b->left_scal, b->pts + pl.slot_h2, b->acc + 0, 8, pl.n_points, n};
+        pr.p[1] = MsmProblem{b->msm_scal, b->pts, b->acc + 1, 8, 1, terms};
+        if ((rc = msm_enqueue_multi(s, b->ws, pr))) return rc;
+    }
     mark();
     if (with_pairing) { if ((rc = pairing_check_enqueue(s, ctx->pairing, b->acc, 1, b->ok))) return rc; }
     mark();
@@ -270,7 +273,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
     hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->acc); hipFree(b->pairs); hipFree(b->ok);
     hipFree(b->out_bytes); hipFree(b->out_ident);
-    b->ws_right.release(); b->ws_left.release();
+    b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     if (b->stream && b->owns_stream) hipStreamDestroy(b->stream);
     delete b;

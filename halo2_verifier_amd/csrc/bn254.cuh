@@ -113,7 +113,7 @@ template <class PR> struct Fp {
 
     // Montgomery product a*b/R mod p (CIOS).  Inputs < p  =>  output < p.
     // Also correct for a < 2^256 (unreduced) with b < p: the running value stays < 2^256 + p.
-    H2V_FN static Fp mul(const Fp& a, const Fp& b) {
+    __host__ __device__ __forceinline__ static Fp mul_inl(const Fp& a, const Fp& b) {
         uint32_t t[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) t[i] = 0;
@@ -143,6 +143,12 @@ template <class PR> struct Fp {
         for (int i = 0; i < 8; ++i) r.v[i] = take_sub ? u[i] : t[i];
         return r;
     }
+    // The same product as a real function call (operands and result by value, i.e. in VGPRs).  Mid-level routines
+    // (Fq2 products, the G1 group law) inline mul_inl so that their independent products can be interleaved by the
+    // scheduler — a lone wave is latency-bound on the carry chains of a single product — while everything else
+    // calls this one copy to keep code size and compile time bounded.
+    H2V_FN static Fp mul(Fp a, Fp b) { return mul_inl(a, b); }
+    __host__ __device__ __forceinline__ Fp sqr_inl() const { return mul_inl(*this, *this); }
     H2V_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
     H2V_HD Fp sqr() const { return mul(*this, *this); }
 

@@ -37,50 +37,55 @@ struct G1J {
     H2V_HD G1J neg() const { G1J r = *this; r.Y = Y.neg(); return r; }
 };
 
+// The group law routines are real functions whose field products are inlined (see Fp::mul).
+#define H2V_M(a, b) Fq::mul_inl((a), (b))
 H2V_FN G1J g1_dbl(const G1J& p) {
     if (p.is_identity()) return p;
-    Fq A = p.X.sqr(), B = p.Y.sqr(), C = B.sqr();
-    Fq D = ((p.X + B).sqr() - A - C).dbl();
-    Fq E = A.dbl() + A, F = E.sqr();
+    Fq A = H2V_M(p.X, p.X), B = H2V_M(p.Y, p.Y), YZ = H2V_M(p.Y, p.Z);
+    Fq C = H2V_M(B, B), XB = p.X + B;
+    Fq D = (H2V_M(XB, XB) - A - C).dbl();
+    Fq E = A.dbl() + A, F = H2V_M(E, E);
     G1J r;
     r.X = F - D.dbl();
-    r.Y = E * (D - r.X) - C.dbl().dbl().dbl();
-    r.Z = (p.Y * p.Z).dbl();
+    r.Y = H2V_M(E, D - r.X) - C.dbl().dbl().dbl();
+    r.Z = YZ.dbl();
     return r;
 }
 
 H2V_FN G1J g1_add(const G1J& p, const G1J& q) {
     if (p.is_identity()) return q;
     if (q.is_identity()) return p;
-    Fq Z1Z1 = p.Z.sqr(), Z2Z2 = q.Z.sqr();
-    Fq U1 = p.X * Z2Z2, U2 = q.X * Z1Z1;
-    Fq S1 = p.Y * q.Z * Z2Z2, S2 = q.Y * p.Z * Z1Z1;
+    Fq Z1Z1 = H2V_M(p.Z, p.Z), Z2Z2 = H2V_M(q.Z, q.Z);
+    Fq U1 = H2V_M(p.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
+    Fq S1 = H2V_M(H2V_M(p.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, p.Z), Z1Z1);
     if (U1 == U2) {
         if (S1 == S2) return g1_dbl(p);
         return G1J::identity();
     }
-    Fq H = U2 - U1, I = H.dbl().sqr(), J = H * I, rr = (S2 - S1).dbl(), V = U1 * I;
+    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_M(H2, H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
+    Fq ZZ = p.Z + q.Z;
     G1J r;
-    r.X = rr.sqr() - J - V.dbl();
-    r.Y = rr * (V - r.X) - (S1 * J).dbl();
-    r.Z = ((p.Z + q.Z).sqr() - Z1Z1 - Z2Z2) * H;
+    r.X = H2V_M(rr, rr) - J - V.dbl();
+    r.Y = H2V_M(rr, V - r.X) - H2V_M(S1, J).dbl();
+    r.Z = H2V_M(H2V_M(ZZ, ZZ) - Z1Z1 - Z2Z2, H);
     return r;
 }
 
 H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) {
     if (q.is_identity()) return p;
     if (p.is_identity()) return G1J::from_affine(q);
-    Fq Z1Z1 = p.Z.sqr();
-    Fq U2 = q.x * Z1Z1, S2 = q.y * p.Z * Z1Z1;
+    Fq Z1Z1 = H2V_M(p.Z, p.Z);
+    Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, p.Z), Z1Z1);
     if (p.X == U2) {
         if (p.Y == S2) return g1_dbl(p);
         return G1J::identity();
     }
-    Fq H = U2 - p.X, HH = H.sqr(), I = HH.dbl().dbl(), J = H * I, rr = (S2 - p.Y).dbl(), V = p.X * I;
+    Fq H = U2 - p.X, HH = H2V_M(H, H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - p.Y).dbl(), V = H2V_M(p.X, I);
+    Fq ZH = p.Z + H;
     G1J r;
-    r.X = rr.sqr() - J - V.dbl();
-    r.Y = rr * (V - r.X) - (p.Y * J).dbl();
-    r.Z = (p.Z + H).sqr() - Z1Z1 - HH;
+    r.X = H2V_M(rr, rr) - J - V.dbl();
+    r.Y = H2V_M(rr, V - r.X) - H2V_M(p.Y, J).dbl();
+    r.Z = H2V_M(ZH, ZH) - Z1Z1 - HH;
     return r;
 }
 
@@ -92,7 +97,7 @@ H2V_FN G1A g1_to_affine(const G1J& p) {
 }
 
 // k * P for a small unsigned k (wave-uniform or per-lane; used in the window reduction)
-H2V_FN G1J g1_mul_u32(const G1J& p, uint32_t k) {
+H2V_HD G1J g1_mul_u32(const G1J& p, uint32_t k) {
     G1J r = G1J::identity();
     for (int i = 31; i >= 0; --i) {
         r = g1_dbl(r);

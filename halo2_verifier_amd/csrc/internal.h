@@ -29,19 +29,28 @@ struct MsmPlan {
 };
 MsmPlan msm_plan(uint32_t n);
 
+// One MSM of a multi-problem launch: term i reads scalars[i * sstride ..+8) and bases[i * bstride]
+struct MsmProblem {
+    const uint32_t* scalars; const G1A* bases; G1J* out;
+    uint32_t sstride, bstride, n;
+};
+#define MSM_MAX_PROBLEMS 16
+struct MsmProblems { MsmProblem p[MSM_MAX_PROBLEMS]; uint32_t count = 0; };
+
 struct MsmWorkspace {
-    uint32_t cap_terms = 0;
-    uint32_t* counts = nullptr;   // [windows * buckets]
-    uint32_t* offsets = nullptr;  // [windows * buckets]
-    uint32_t* cursor = nullptr;   // [windows * buckets]
-    uint32_t* list = nullptr;     // [cap_terms * max_windows]
-    G1J* bucket_pts = nullptr;    // [windows * buckets]
-    G1J* window_sums = nullptr;   // [max_windows]
+    uint32_t cap_terms = 0, cap_problems = 0;
+    uint32_t* counts = nullptr;   // [problems * windows * buckets + 1]  (last word: number of heavy buckets)
+    uint32_t* offsets = nullptr;  // [problems * windows * buckets]
+    uint32_t* cursor = nullptr;   // scatter cursors, then the heavy-bucket list
+    uint32_t* list = nullptr;     // term indices sorted by (problem, window, bucket)
+    G1J* bucket_pts = nullptr;    // [problems * windows * buckets]
+    G1J* window_sums = nullptr;   // [problems * windows]
     size_t cap_buckets = 0, cap_list = 0;
-    int alloc(uint32_t max_terms);
+    int alloc(uint32_t max_total_terms, uint32_t max_problems);
     void release();
 };
-// Enqueue sum_i scalars[i] * bases[i] -> *out (Jacobian, device memory).  Asynchronous on `s`.
+// Enqueue all problems of `pr` (each: sum_i scalars[i] * bases[i] -> *out, Jacobian, device memory).  Asynchronous on `s`.
+int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr);
 int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, const G1A* d_bases, uint32_t n, G1J* d_out);
 
 // ------------------------------------------------------------------ small helpers (util.hip)

@@ -1,8 +1,19 @@
 // Final pairing check kernel:  e(left, s_g2) * e(right, -g2) == 1  (DualMSM::check,
-// poly/kzg/msm.rs:185-203).  One lane per independent check: the batch path launches a single
-// check per batch (AccumulatorStrategy), the per-proof path (SingleStrategy) one per proof.
-// The G2 side is constant per context, so its Miller-loop line coefficients are precomputed
-// once on the host (g2_prepare) and only evaluated at the two G1 points here.
+// poly/kzg/msm.rs:185-203).
+//
+// One WAVE per check.  A pairing is a strictly sequential chain of ~550 Fq12 products (Miller loop over 6x+2,
+// then the final exponentiation); on a single lane that is ~20 000 dependent Fq products ~ 50 ms, and a batch
+// ends with exactly one of them.  Here an Fq12 element lives in LDS as six Fq2 coefficients of
+// Fq2[w]/(w^6 - xi), and each product is spread over the wave: lane (i, j) of 36 computes a_i * b_j (one Fq2
+// product = 3 Fq products), the 36 partial products go through LDS, and six lanes fold them with the
+// w^6 = xi reduction.  The chain becomes ~550 x (one Fq2 product + a 6-term fold).
+//
+// The G2 side is constant per context, so its Miller-loop line coefficients are precomputed once on the host
+// (g2_prepare); the wave evaluates them at the two G1 points up front, all lines in parallel, into LDS.
+// The G1 points are used projectively (line values scaled by Z^3 in Fq*, which the final exponentiation kills),
+// so no field inversion is needed for them.
+//
+// SingleStrategy (one check per proof) launches one such wave per proof.
 #include "../../include/h2v.h"
 #include "internal.h"
 #include "pairing.cuh"
@@ -10,19 +21,149 @@
 
 namespace h2v {
 
-__global__ void __launch_bounds__(64) k_pairing_check(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
-                                                      const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
-                                                      uint32_t* __restrict__ ok) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    G1A left = g1_to_affine(pairs[2 * i]), right = g1_to_affine(pairs[2 * i + 1]);
-    Fq12 f = miller_loop_2(left, l_sg2, right, l_ng2);
-    ok[i] = final_exp_is_one(f, *consts) ? 1u : 0u;
+#define N_LINES 102  // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
+
+struct WaveShared {
+    Fq2 line[2][N_LINES][3];  // per pair: coefficient of w^0, w^1, w^3 of every line, already evaluated at P
+    Fq2 prod[36];
+    Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6], L[6];
+};
+
+// dst = x * y in Fq2[w]/(w^6 - xi); dst may alias x or y
+__device__ __forceinline__ void wmul(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {
+    if (lane < 36) s.prod[lane] = Fq2::mul(x[lane / 6], y[lane % 6]);
+    __syncthreads();
+    if (lane < 6) {
+        Fq2 lo = Fq2::zero(), hi = Fq2::zero();
+        for (uint32_t i = 0; i < 6; ++i) {
+            if (i <= lane) lo = lo + s.prod[i * 6 + (lane - i)];
+            else hi = hi + s.prod[i * 6 + (lane + 6 - i)];
+        }
+        dst[lane] = lo + hi.mul_xi();
+    }
+    __syncthreads();
+}
+// multiply by a line: only the w^0, w^1, w^3 coefficients of y are non-zero
+__device__ __forceinline__ void wmul_line(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* l3, uint32_t lane) {
+    if (lane < 18) {
+        const uint32_t i = lane / 3, jj = lane % 3, j = jj == 2 ? 3 : jj;
+        s.prod[i * 6 + j] = Fq2::mul(x[i], l3[jj]);
+    }
+    __syncthreads();
+    if (lane < 6) {
+        Fq2 lo = Fq2::zero(), hi = Fq2::zero();
+        for (uint32_t i = 0; i < 6; ++i) {
+            uint32_t j = i <= lane ? lane - i : lane + 6 - i;
+            if (j != 0 && j != 1 && j != 3) continue;
+            if (i <= lane) lo = lo + s.prod[i * 6 + j];
+            else hi = hi + s.prod[i * 6 + j];
+        }
+        dst[lane] = lo + hi.mul_xi();
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void wcopy(Fq2* dst, const Fq2* src, uint32_t lane) { if (lane < 6) dst[lane] = src[lane]; __syncthreads(); }
+// x -> x^(p^6): w -> -w
+__device__ __forceinline__ void wconj(Fq2* dst, const Fq2* src, uint32_t lane) { if (lane < 6) dst[lane] = (lane & 1) ? src[lane].neg() : src[lane]; __syncthreads(); }
+// x -> x^p
+__device__ __forceinline__ void wfrob(Fq2* dst, const Fq2* src, const PairingConsts* k, uint32_t lane) {
+    if (lane < 6) { Fq2 c = src[lane].conj(); dst[lane] = lane == 0 ? c : Fq2::mul(c, k->gamma1[lane]); }
+    __syncthreads();
+}
+// tower view: c0 = (a0, a2, a4), c1 = (a1, a3, a5)
+__device__ __noinline__ void winv_lane0(Fq2* dst, const Fq2* src) {
+    Fq12 t;
+    t.c0 = {src[0], src[2], src[4]}; t.c1 = {src[1], src[3], src[5]};
+    t = t.inv();
+    dst[0] = t.c0.c0; dst[2] = t.c0.c1; dst[4] = t.c0.c2; dst[1] = t.c1.c0; dst[3] = t.c1.c1; dst[5] = t.c1.c2;
+}
+// dst = x^BN_X (x in the cyclotomic subgroup); tmp is scratch; dst must not alias x
+__device__ __forceinline__ void wpow_x(WaveShared& s, Fq2* dst, const Fq2* x, uint32_t lane) {
+    wcopy(dst, x, lane);
+    for (int i = 61; i >= 0; --i) {
+        wmul(s, dst, dst, dst, lane);
+        if ((BN_X >> i) & 1) wmul(s, dst, dst, x, lane);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
+                                                     const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
+                                                     uint32_t* __restrict__ ok) {
+    __shared__ WaveShared s;
+    const uint32_t chk = blockIdx.x, lane = threadIdx.x;
+    if (chk >= n) return;
+    const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
+    const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
+    // line l(P) = a*y + b*x*w + c*w^3 with (x, y) = (X/Z^2, Y/Z^3); scaled by Z^3: a*Y + b*X*Z*w + c*Z^3*w^3
+    const Fq xz0 = P0.X * P0.Z, z30 = P0.Z.sqr() * P0.Z, xz1 = P1.X * P1.Z, z31 = P1.Z.sqr() * P1.Z;
+    for (uint32_t t = lane; t < 2 * N_LINES; t += 64) {
+        const uint32_t pr = t / N_LINES, li = t % N_LINES;
+        const LineCoeff c = pr ? l_ng2[li] : l_sg2[li];
+        s.line[pr][li][0] = c.a.scale(pr ? P1.Y : P0.Y);
+        s.line[pr][li][1] = c.b.scale(pr ? xz1 : xz0);
+        s.line[pr][li][2] = c.c.scale(pr ? z31 : z30);
+    }
+    if (lane < 6) s.f[lane] = lane == 0 ? Fq2::one() : Fq2::zero();
+    __syncthreads();
+    // Miller loop
+    uint32_t idx = 0;
+    for (int i = 63; i >= 0; --i) {
+        wmul(s, s.f, s.f, s.f, lane);
+        if (!skip0) wmul_line(s, s.f, s.f, s.line[0][idx], lane);
+        if (!skip1) wmul_line(s, s.f, s.f, s.line[1][idx], lane);
+        ++idx;
+        if ((ATE_LOW >> i) & 1) {
+            if (!skip0) wmul_line(s, s.f, s.f, s.line[0][idx], lane);
+            if (!skip1) wmul_line(s, s.f, s.f, s.line[1][idx], lane);
+            ++idx;
+        }
+    }
+    for (int t = 0; t < 2; ++t, ++idx) {
+        if (!skip0) wmul_line(s, s.f, s.f, s.line[0][idx], lane);
+        if (!skip1) wmul_line(s, s.f, s.f, s.line[1][idx], lane);
+    }
+    // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
+    if (lane == 0) winv_lane0(s.t0, s.f);
+    __syncthreads();
+    wconj(s.t1, s.f, lane);
+    wmul(s, s.r, s.t1, s.t0, lane);            // f^(p^6 - 1)
+    wfrob(s.t0, s.r, consts, lane);
+    wfrob(s.t0, s.t0, consts, lane);
+    wmul(s, s.r, s.t0, s.r, lane);             // ^(p^2 + 1)
+    // hard part (same chain as final_exp_is_one in pairing.cuh)
+    Fq2 *y0 = s.t0, *y1 = s.t1, *y3 = s.t2, *y4 = s.t3, *y6 = s.t4, *u = s.t5, *v = s.t6;
+    wpow_x(s, y0, s.r, lane); wconj(y0, y0, lane);               // y0 = r^-x
+    wmul(s, y1, y0, y0, lane);                                   // y1 = y0^2
+    wmul(s, u, y1, y1, lane);                                    // y2 = y1^2
+    wmul(s, y3, u, y1, lane);                                    // y3 = y2 * y1
+    wpow_x(s, y4, y3, lane); wconj(y4, y4, lane);                // y4 = y3^-x
+    wmul(s, u, y4, y4, lane);                                    // y5 = y4^2
+    wpow_x(s, y6, u, lane); wconj(y6, y6, lane);                 // y6 = y5^-x
+    wconj(y3, y3, lane);
+    wconj(y6, y6, lane);
+    wmul(s, u, y6, y4, lane);                                    // y7 = y6 * y4
+    wmul(s, u, u, y3, lane);                                     // y8 = y7 * y3          (u = y8)
+    wmul(s, v, u, y1, lane);                                     // y9 = y8 * y1          (v = y9)
+    wmul(s, y0, u, y4, lane);                                    // y10 = y8 * y4
+    wmul(s, y0, y0, s.r, lane);                                  // y11 = y10 * r         (y0 = y11)
+    wfrob(y1, v, consts, lane);                                  // y12 = y9^p
+    wmul(s, y0, y1, y0, lane);                                   // y13 = y12 * y11       (y0 = y13)
+    wfrob(u, u, consts, lane); wfrob(u, u, consts, lane);        // y8^(p^2)
+    wmul(s, y0, u, y0, lane);                                    // y14 = y8' * y13       (y0 = y14)
+    wconj(y1, s.r, lane);
+    wmul(s, y1, y1, v, lane);                                    // conj(r) * y9
+    wfrob(y1, y1, consts, lane); wfrob(y1, y1, consts, lane); wfrob(y1, y1, consts, lane);  // y15
+    wmul(s, y0, y1, y0, lane);                                   // y16 = y15 * y14
+    if (lane == 0) {
+        bool one = y0[0] == Fq2::one();
+        for (int k2 = 1; k2 < 6; ++k2) one = one && y0[k2].is_zero();
+        ok[chk] = one ? 1u : 0u;
+    }
 }
 
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, d_ok);
+    hipLaunchKernelGGL(k_pairing_wave, dim3(n), dim3(64), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
