@@ -24,6 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# A batch's tail (window Horner, pairing) is one or two waves; throughput comes from many batches in flight, each on
+# its own HIP stream.  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), which
+# would serialise most of them; ask for 16 before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 K_CIRCUIT = 14
 N_PUBLIC = 8
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -74,10 +79,10 @@ def cpu_baseline(d, sample, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--depth", type=int, default=8, help="batches in flight per GPU")
+    ap.add_argument("--depth", type=int, default=32, help="batches in flight per GPU")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
