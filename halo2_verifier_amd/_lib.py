@@ -56,6 +56,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 under the same soname as the
+    # system one this library links against.  Whichever is loaded first serves both, and PyTorch cannot enumerate
+    # GPUs on top of the system copy ("No HIP GPUs are available").  If PyTorch is installed, let it load its runtime first.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise H2VError(-18, f"{path} not found: build it with `make -C halo2_verifier_amd/csrc` "

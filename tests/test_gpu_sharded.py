@@ -1,0 +1,100 @@
+"""The N > 1 path on one GPU: R shards of one batch, each run through the staged C ABI with the draw tail of its
+global position (h2v_batch_upload rand32_tail), accumulators exported and folded by h2v_batch_fold_check_enqueue —
+the exact call sequence bench.py issues per rank, minus the RCCL all-gather (covered on gloo by
+tests/test_distributed_gloo.py).  The folded result must equal the unsharded h2v_verify_batch bit for bit, for any R.
+
+Also the BASELINE.json-size checks (1024 proofs): determinism, sharding invariance, and single-proof tampering."""
+import random
+
+import pytest
+
+import circuits
+from circuits import R_MOD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    """1024 distinct proofs of the bench VK shape (k = 8 here: verifier work does not depend on k)."""
+    s = circuits.setup_vector_mul(8, 8)
+    P, I = circuits.prove_vector_mul_batch(s, 1024, seed=1234, threads=16)
+    yield s, P, I
+    s.free()
+
+
+def _sharded(ctx, P, I, rand, R):
+    import torch
+    import halo2_verifier_amd as h2v
+    from halo2_verifier_amd import distributed as h2d
+    total = len(P)
+    rand_all = b"".join(r.to_bytes(32, "little") for r in rand)
+    acc = torch.zeros(R * h2d.ACC_BYTES, dtype=torch.uint8, device="cuda:0")
+    statuses = []
+    batches = []
+    for r in range(R):
+        lo, hi = h2d.shard_bounds(total, R, r)
+        b = h2v.Batch(ctx, max(hi - lo, 1), 8)
+        flat = b"".join(P[lo:hi])
+        inst = b"".join(b"".join(col) for i in I[lo:hi] for col in i)
+        b.upload(flat, 1024, inst, [8], h2d.tail_for_shard(rand_all, lo))
+        b.launch(with_pairing=False)
+        ok, st, _, _ = b.finish()
+        statuses += st
+        b.export_accumulators(acc.data_ptr() + r * h2d.ACC_BYTES)
+        b.finish()
+        batches.append(b)
+    torch.cuda.synchronize()
+    batches[0].fold_check_enqueue(acc.data_ptr(), R)
+    ok, _, left, right = batches[0].finish()
+    for b in batches:
+        b.close()
+    return ok and not any(statuses), statuses, left, right
+
+
+def _ctx(s):
+    import halo2_verifier_amd as h2v
+    return h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 8])
+def test_sharded_equals_unsharded(big, R):
+    s, P, I = big
+    ctx = _ctx(s)
+    n = 100
+    rnd = random.Random(R)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    ref = ctx.verify_batch(P[:n], I[:n], rand)
+    got = _sharded(ctx, P[:n], I[:n], rand, R)
+    assert got == ref and got[0] is True
+    ctx.close()
+
+
+def test_full_size_batch_properties(big):
+    """1024 proofs (BASELINE.json config 2): determinism, sharding invariance at 8 shards, oracle agreement on the
+    accumulators, and rejection + localisation of a single tampered proof."""
+    s, P, I = big
+    ctx = _ctx(s)
+    rnd = random.Random(77)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(1024)]
+    a = ctx.verify_batch(P, I, rand)
+    b = ctx.verify_batch(P, I, rand)
+    assert a == b and a[0] is True and a[1] == [0] * 1024
+    assert _sharded(ctx, P, I, rand, 8) == a
+    assert circuits.oracle_verify_batch(s, P, I, rand) == a            # bit-exact against the CPU oracle at full size (~2 s of CPU)
+    # different draws, same proofs: still accepted, different accumulators
+    rand2 = [rnd.randrange(1, R_MOD) for _ in range(1024)]
+    c = ctx.verify_batch(P, I, rand2)
+    assert c[0] is True and (c[2], c[3]) != (a[2], a[3])
+    # one wrong public input among 1024: the batch is rejected; SingleStrategy pins it to the proof
+    I2 = list(I)
+    I2[517] = [[circuits.le32(1)] + I[517][0][1:]]
+    d = ctx.verify_batch(P, I2, rand)
+    assert d[0] is False and d[1] == [0] * 1024
+    each = ctx.verify_each(P[512:520], I2[512:520])
+    assert each == [0, 0, 0, 0, 0, -2, 0, 0]
+    # OS-drawn multipliers (rand32 = NULL): accepted, and two runs disagree on the accumulators
+    e1 = ctx.verify_batch(P[:64], I[:64], None)
+    e2 = ctx.verify_batch(P[:64], I[:64], None)
+    assert e1[0] and e2[0] and (e1[2], e1[3]) != (e2[2], e2[3])
+    ctx.close()
