@@ -100,10 +100,18 @@ def main():
 
     if not torch.cuda.is_available() or h2v.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # rehearsal knobs (not used by the driver): H2V_BENCH_BACKEND=gloo and H2V_BENCH_ONE_DEVICE=1 run an N-rank job on a
+    # single-GPU box (all ranks on cuda:0, collectives staged through the host) to exercise the multi-rank control flow
+    backend = os.environ.get("H2V_BENCH_BACKEND", "nccl")
+    if os.environ.get("H2V_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # inputs: rank 0 generates (or loads) the proofs, the others wait and read the cache
     if rank == 0:
@@ -199,6 +207,15 @@ def main():
         n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
         terms_total = n_local * shape["n_points"] + n_shared + n_local
         msm_ms = stages["msm"]
+        # HBM traffic of the MSM stage per launch comes from the committed PMC profile of this same workload
+        # (separate rocprofv3 --pmc passes cannot run inside the timed region); null if it does not match this shape
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_msm_traffic.json")))
+            if tj.get("terms_per_launch") == terms_total:
+                traffic = tj["msm_stage_traffic_bytes_per_launch"]
+        except Exception:
+            pass
         achieved = (96.0 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
         out = {
             "metric": "proofs verified/sec (BN254, k=14)",
@@ -216,7 +233,7 @@ def main():
             "config": {"workload": f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
                                    f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step), {args.distinct} distinct proofs",
                        "proofs_per_gpu_per_step": B, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "MSM stage (msm_count/scan/scatter/bucket/window/final, both channels)", "terms_per_launch": terms_total,
                          "mean_stage_ms": msm_ms},
             "stages_ms": stages,
