@@ -37,9 +37,11 @@ struct G1J {
     H2V_HD G1J neg() const { G1J r = *this; r.Y = Y.neg(); return r; }
 };
 
-// The group law routines are real functions whose field products are inlined (see Fp::mul).
+// The group law routines come in two forms: *_inl bodies that hot kernels inline so that the accumulator stays in
+// registers, and plain functions (real calls) for everything else.  Field products are inlined in both (see Fp::mul).
+H2V_FN G1J g1_dbl(const G1J& p);
 #define H2V_M(a, b) Fq::mul_inl((a), (b))
-H2V_FN G1J g1_dbl(const G1J& p) {
+__host__ __device__ __forceinline__ G1J g1_dbl_inl(const G1J& p) {
     if (p.is_identity()) return p;
     Fq A = H2V_M(p.X, p.X), B = H2V_M(p.Y, p.Y), YZ = H2V_M(p.Y, p.Z);
     Fq C = H2V_M(B, B), XB = p.X + B;
@@ -52,14 +54,14 @@ H2V_FN G1J g1_dbl(const G1J& p) {
     return r;
 }
 
-H2V_FN G1J g1_add(const G1J& p, const G1J& q) {
+__host__ __device__ __forceinline__ G1J g1_add_inl(const G1J& p, const G1J& q) {
     if (p.is_identity()) return q;
     if (q.is_identity()) return p;
     Fq Z1Z1 = H2V_M(p.Z, p.Z), Z2Z2 = H2V_M(q.Z, q.Z);
     Fq U1 = H2V_M(p.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
     Fq S1 = H2V_M(H2V_M(p.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, p.Z), Z1Z1);
     if (U1 == U2) {
-        if (S1 == S2) return g1_dbl(p);
+        if (S1 == S2) return g1_dbl(p);  // (rare) doubling path stays a call
         return G1J::identity();
     }
     Fq H = U2 - U1, H2 = H.dbl(), I = H2V_M(H2, H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
@@ -71,7 +73,7 @@ H2V_FN G1J g1_add(const G1J& p, const G1J& q) {
     return r;
 }
 
-H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) {
+__host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1A& q) {
     if (q.is_identity()) return p;
     if (p.is_identity()) return G1J::from_affine(q);
     Fq Z1Z1 = H2V_M(p.Z, p.Z);
@@ -88,6 +90,10 @@ H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) {
     r.Z = H2V_M(ZH, ZH) - Z1Z1 - HH;
     return r;
 }
+
+H2V_FN G1J g1_dbl(const G1J& p) { return g1_dbl_inl(p); }
+H2V_FN G1J g1_add(const G1J& p, const G1J& q) { return g1_add_inl(p, q); }
+H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) { return g1_add_affine_inl(p, q); }
 
 H2V_FN G1A g1_to_affine(const G1J& p) {
     if (p.is_identity()) return G1A::identity();

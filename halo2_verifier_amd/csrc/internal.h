@@ -24,8 +24,8 @@ void set_last_error(const std::string& s);
 struct MsmPlan {
     uint32_t n;        // terms
     uint32_t c;        // window bits
-    uint32_t windows;  // ceil(254 / c)
-    uint32_t buckets;  // 2^c - 1 per window
+    uint32_t windows;  // ceil(129 / c): GLV halves are 128-bit magnitudes, +1 bit for the signed-digit carry
+    uint32_t buckets;  // 2^(c-1) per window (signed digits)
 };
 MsmPlan msm_plan(uint32_t n);
 

@@ -6,6 +6,10 @@
 // evaluates several independent MSMs ("problems": the left and right channel of a batch) in
 // one set of launches:
 //
+//   0. (inside 1 and 3) GLV: k = k1 + k2*lambda with |k1|, |k2| < 2^128, k2 acting on phi(P) = (beta*x, y); both halves are
+//                   recoded into SIGNED c-bit digits, so a 254-bit scalar costs 2*ceil(129/c) bucket entries over
+//                   ceil(129/c) windows of 2^(c-1) buckets (instead of ceil(254/c) windows of 2^c - 1): half the windows
+//                   to reduce and half the doublings in the final Horner chain
 //   1. msm_count    one lane per term: extract every window's digit, histogram (problem,window,bucket)
 //   2. msm_scan     exclusive prefix sum of the histogram (one workgroup)
 //   3. msm_scatter  one lane per term: counting-sort term indices into per-bucket lists
@@ -36,12 +40,12 @@ namespace h2v {
 #define MSM_HEAVY_THREADS 256
 
 MsmPlan msm_plan(uint32_t n) {
-    MsmPlan best{n, 2, 127, 3};
+    MsmPlan best{n, 2, 65, 2};
     double best_cost = 1e300;
-    for (uint32_t c = 2; c <= 14; ++c) {
-        uint32_t w = (254 + c - 1) / c;
-        uint32_t b = (1u << c) - 1;
-        double cost = (double)w * ((double)n + 2.0 * b);
+    for (uint32_t c = 2; c <= 15; ++c) {
+        uint32_t w = (130 + c - 1) / c;        // magnitudes < 2^128 (+1 bit of slack) + the carry of the signed recoding
+        uint32_t b = 1u << (c - 1);
+        double cost = (double)w * (2.0 * n + 2.0 * b);
         if (cost < best_cost) { best_cost = cost; best = MsmPlan{n, c, w, b}; }
     }
     return best;
@@ -54,7 +58,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems) {
     for (uint32_t n = 1; n <= max_terms; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n); mb = std::max(mb, (size_t)p.windows * p.buckets); }
     { MsmPlan p = msm_plan(max_terms); mb = std::max(mb, (size_t)p.windows * p.buckets); }
     mb *= max_problems;
-    cap_buckets = mb; cap_list = (size_t)max_terms * 127;  // c >= 2  =>  windows <= 127; max_terms = total terms over all problems
+    cap_buckets = mb; cap_list = (size_t)max_terms * 130;  // c >= 2  =>  2 halves x <= 65 windows; max_terms = total terms over all problems
     H2V_HIP_CHECK(hipMalloc(&counts, (mb + 1) * 4));
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&cursor, mb * 4));
@@ -74,12 +78,76 @@ void MsmWorkspace::release() {
     cap_terms = 0; cap_problems = 0;
 }
 
-__device__ __forceinline__ uint32_t msm_digit(const uint32_t* __restrict__ s, uint32_t w, uint32_t c) {
+// ---- GLV decomposition for BN254 G1 (constants derived in DESIGN.md section 4; lattice basis (a1, b1), (a2, b2) with
+// a_i + b_i*lambda = 0 mod r; g_i = floor(2^256 * {b2, -b1} / r))
+__device__ __forceinline__ void mul_lo5(uint32_t out[5], const uint32_t* a, int na, const uint32_t* b, int nb) {  // a*b mod 2^160
+    uint64_t acc[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < na && i < 5; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < nb && i + j < 5; ++j) {
+            uint64_t t = (uint64_t)a[i] * b[j] + (uint32_t)acc[i + j] + carry;
+            acc[i + j] = (uint32_t)t; carry = t >> 32;
+        }
+    }
+    for (int i = 0; i < 5; ++i) out[i] = (uint32_t)acc[i];
+}
+// (k * g) >> 256 for a 5-limb g; result < 2^130 in 5 limbs
+__device__ __forceinline__ void mul_hi256(uint32_t out[5], const uint32_t k[8], const uint32_t g[5]) {
+    uint32_t t[13];
+    for (int i = 0; i < 13; ++i) t[i] = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 5; ++j) {
+            uint64_t v = (uint64_t)k[i] * g[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)v; carry = v >> 32;
+        }
+        t[i + 5] = (uint32_t)carry;
+    }
+    for (int i = 0; i < 5; ++i) out[i] = t[8 + i];
+}
+struct GlvHalf { uint32_t mag[5]; bool neg; };  // |k_i| < 2^128 (limb 4 only ever holds the recoding carry)
+__device__ __forceinline__ void glv_finish(GlvHalf& h, uint32_t t[5]) {  // t = two's complement mod 2^160
+    h.neg = (t[4] >> 31) != 0;
+    if (h.neg) { uint64_t c = 1; for (int i = 0; i < 5; ++i) { uint64_t v = (uint64_t)(~t[i]) + c; t[i] = (uint32_t)v; c = v >> 32; } }
+    for (int i = 0; i < 5; ++i) h.mag[i] = t[i];
+}
+__device__ __forceinline__ void glv_decompose(const uint32_t* __restrict__ k, GlvHalf& h1, GlvHalf& h2) {
+    const uint32_t A1[5] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u, 0u};   //  a1
+    const uint32_t B1N[5] = {0x94d213e3u, 0x89d32568u, 0u, 0u, 0u};                     // -b1 ( = a2 )
+    const uint32_t B2[5] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u, 0u};    //  b2
+    const uint32_t G1[5] = {0x00ff6565u, 0x5398fd03u, 0xa773d2d2u, 0x4ccef014u, 0x2u};
+    const uint32_t G2[5] = {0xc7e0b3d7u, 0xd91d232eu, 0x2u, 0u, 0u};
+    uint32_t kk[8];
+    for (int i = 0; i < 8; ++i) kk[i] = k[i];
+    uint32_t c1[5], c2[5], p1[5], p2[5], t[5];
+    mul_hi256(c1, kk, G1);
+    mul_hi256(c2, kk, G2);
+    // k1 = k - c1*a1 - c2*a2
+    mul_lo5(p1, c1, 5, A1, 5); mul_lo5(p2, c2, 5, B1N, 5);
+    {
+        int64_t borrow = 0;
+        for (int i = 0; i < 5; ++i) { int64_t v = (int64_t)kk[i] - p1[i] - p2[i] + borrow; t[i] = (uint32_t)v; borrow = v >> 32; }
+    }
+    glv_finish(h1, t);
+    // k2 = -c1*b1 - c2*b2 = c1*(-b1) - c2*b2
+    mul_lo5(p1, c1, 5, B1N, 5); mul_lo5(p2, c2, 5, B2, 5);
+    {
+        int64_t borrow = 0;
+        for (int i = 0; i < 5; ++i) { int64_t v = (int64_t)p1[i] - p2[i] + borrow; t[i] = (uint32_t)v; borrow = v >> 32; }
+    }
+    glv_finish(h2, t);
+}
+__device__ __forceinline__ uint32_t raw_window(const uint32_t m[5], uint32_t w, uint32_t c) {
     uint32_t off = w * c, word = off >> 5, sh = off & 31;
-    uint32_t v = s[word] >> sh;
-    if (sh + c > 32 && word + 1 < 8) v |= s[word + 1] << (32 - sh);
+    if (word >= 5) return 0;
+    uint32_t v = m[word] >> sh;
+    if (sh + c > 32 && word + 1 < 5) v |= m[word + 1] << (32 - sh);
     return v & ((1u << c) - 1);
 }
+// entry of the sorted list: term index | half << 30 | negate << 31
+#define MSM_ENTRY_HALF 0x40000000u
+#define MSM_ENTRY_NEG 0x80000000u
+#define MSM_ENTRY_TERM 0x3fffffffu
 
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) msm_count_or_scatter(MsmProblems pr, MsmPlan p, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
@@ -87,23 +155,48 @@ __global__ void __launch_bounds__(256) msm_count_or_scatter(MsmProblems pr, MsmP
     uint32_t q = blockIdx.y;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pr.p[q].n) return;
-    const uint32_t* s = pr.p[q].scalars + (size_t)pr.p[q].sstride * t;  // digits are read straight from L1/L2: no runtime-indexed register array
+    const uint32_t* s = pr.p[q].scalars + (size_t)pr.p[q].sstride * t;
+    uint32_t nz = 0;
+    for (int i = 0; i < 8; ++i) nz |= s[i];
+    if (!nz) return;  // zero scalar (e.g. a point slot the channel does not use)
     const uint32_t* bw = reinterpret_cast<const uint32_t*>(pr.p[q].bases + (size_t)pr.p[q].bstride * t);
     uint32_t any = 0;
     for (int i = 0; i < 16; ++i) any |= bw[i];
     if (!any) return;  // identity bases contribute nothing
+    GlvHalf h[2];
+    glv_decompose(s, h[0], h[1]);
     uint32_t nbq = p.windows * p.buckets;
-    for (uint32_t w = 0; w < p.windows; ++w) {
-        uint32_t d = msm_digit(s, w, p.c);
-        if (!d) continue;
-        uint32_t b = q * nbq + w * p.buckets + d - 1;
-        if (SCATTER) {
-            uint32_t pos = atomicAdd(&cursor[b], 1u);
-            list[offsets[b] + pos] = t;
-        } else {
-            atomicAdd(&counts[b], 1u);
+    const uint32_t half_range = 1u << (p.c - 1);
+    for (uint32_t hf = 0; hf < 2; ++hf) {
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < p.windows; ++w) {
+            uint32_t raw = raw_window(h[hf].mag, w, p.c) + carry;
+            bool neg_digit = raw > half_range;       // digit = raw - 2^c, carry into the next window
+            uint32_t mag = neg_digit ? (1u << p.c) - raw : raw;
+            carry = neg_digit ? 1u : 0u;
+            if (!mag) continue;
+            uint32_t b = q * nbq + w * p.buckets + mag - 1;
+            if (SCATTER) {
+                uint32_t pos = atomicAdd(&cursor[b], 1u);
+                list[offsets[b] + pos] = t | (hf ? MSM_ENTRY_HALF : 0u) | ((neg_digit != h[hf].neg) ? MSM_ENTRY_NEG : 0u);
+            } else {
+                atomicAdd(&counts[b], 1u);
+            }
         }
     }
+}
+
+// the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y)
+__device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) {
+    G1A b = q.bases[(size_t)(e & MSM_ENTRY_TERM) * q.bstride];
+    if (e & MSM_ENTRY_HALF) {
+        Fq beta;  // Montgomery form of the cube root of unity 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
+        beta.v[0] = 0x13e80b9cu; beta.v[1] = 0x3350c88eu; beta.v[2] = 0xdb5e56b9u; beta.v[3] = 0x7dce557cu;
+        beta.v[4] = 0xb615564au; beta.v[5] = 0x6001b4b8u; beta.v[6] = 0x020217e0u; beta.v[7] = 0x2682e617u;
+        b.x = Fq::mul(b.x, beta);
+    }
+    if (e & MSM_ENTRY_NEG) b.y = b.y.neg();
+    return b;
 }
 
 // exclusive scan of counts[0..nb) -> offsets; zeroes cursor.  One workgroup of 1024 lanes.
@@ -135,7 +228,7 @@ __global__ void __launch_bounds__(64) msm_bucket(MsmProblems pr, uint32_t nbq, u
     if (cnt > MSM_HEAVY) { heavy[atomicAdd(&counts[nb], 1u)] = b; return; }
     const MsmProblem q = pr.p[b / nbq];
     G1J acc = G1J::identity();
-    for (uint32_t i = 0; i < cnt; ++i) acc = g1_add_affine(acc, q.bases[(size_t)list[off + i] * q.bstride]);
+    for (uint32_t i = 0; i < cnt; ++i) acc = g1_add_affine_inl(acc, msm_entry_base(q, list[off + i]));
     bucket_pts[b] = acc;
 }
 
@@ -151,7 +244,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_heavy(MsmProblems pr, u
         uint32_t cnt = counts[b], off = offsets[b];
         const MsmProblem q = pr.p[b / nbq];
         G1J acc = G1J::identity();
-        for (uint32_t i = t; i < cnt; i += MSM_HEAVY_THREADS) acc = g1_add_affine(acc, q.bases[(size_t)list[off + i] * q.bstride]);
+        for (uint32_t i = t; i < cnt; i += MSM_HEAVY_THREADS) acc = g1_add_affine(acc, msm_entry_base(q, list[off + i]));
         red[t] = acc;
         __syncthreads();
         for (uint32_t d = MSM_HEAVY_THREADS / 2; d > 0; d >>= 1) {
@@ -171,8 +264,8 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restr
     G1J run = G1J::identity(), sum = G1J::identity();
     const G1J* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
     for (uint32_t b = hi; b > lo; --b) {
-        run = g1_add(run, bp[b - 1]);
-        sum = g1_add(sum, run);
+        run = g1_add_inl(run, bp[b - 1]);
+        sum = g1_add_inl(sum, run);
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1)
     if (lo < hi && lo > 0) {
@@ -198,7 +291,7 @@ __global__ void __launch_bounds__(64) msm_final(const G1J* __restrict__ window_s
     G1J acc = G1J::identity();
     if (pr.p[q].n) {
         for (int w = (int)p.windows - 1; w >= 0; --w) {
-            for (uint32_t i = 0; i < p.c; ++i) acc = g1_dbl(acc);
+            for (uint32_t i = 0; i < p.c; ++i) acc = g1_dbl_inl(acc);
             acc = g1_add(acc, window_sums[(size_t)q * p.windows + w]);
         }
     }
@@ -215,10 +308,11 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
         H2V_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    if (nmax > MSM_ENTRY_TERM) { set_last_error("msm_enqueue_multi: more than 2^30 terms in one problem"); return H2V_ERR_BAD_ARGUMENT; }
     if (total > ws.cap_terms) { set_last_error("msm_enqueue_multi: terms exceed workspace capacity"); return H2V_ERR_BAD_ARGUMENT; }
     MsmPlan p = msm_plan(nmax);
     uint32_t nbq = p.windows * p.buckets, nb = nbq * pr.count;
-    if (nb > ws.cap_buckets || total * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
+    if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 1) * 4, s));
     dim3 gt((nmax + 255) / 256, pr.count);
     hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(256), 0, s, pr, p, ws.counts, ws.offsets, ws.cursor, ws.list);
