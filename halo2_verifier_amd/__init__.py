@@ -9,6 +9,6 @@ raises ``H2VError`` unless the library and a HIP device are present.
 from ._lib import H2VError, lib_path, load_library, device_count  # noqa: F401
 from .verifier import (  # noqa: F401
     SerdeFormat, ParamsKZG, VerifyingKey, Context, AccumulatorStrategy, SingleStrategy, verify_proof, verify_batch,
-    PlonkError, Batch,
+    PlonkError, Batch, MultiOpen, TranscriptKind,
 )
 from . import distributed  # noqa: F401

@@ -28,6 +28,7 @@ SIGNATURES = {
     "h2v_device_count": (c_int, []),
     "h2v_last_error": (ctypes.c_char_p, []),
     "h2v_ctx_create": (c_int, [c_u8p, c_sz, c_int, c_u8p, c_sz, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "h2v_ctx_create_ex": (c_int, [c_u8p, c_sz, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, ctypes.POINTER(c_vp)]),
     "h2v_ctx_destroy": (None, [c_vp]),
     "h2v_ctx_proof_shape": (c_int, [c_vp, c_szp, c_szp, c_szp, c_szp, c_szp]),
     "h2v_msm_g1": (c_int, [c_vp, c_u8p, c_u8p, c_sz, c_u8p, c_intp]),

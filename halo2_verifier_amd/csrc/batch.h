@@ -33,8 +33,8 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, Fr* d_mult);
 int frvm_enqueue(hipStream_t s, const FrvmArgs& a);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t* d_msm_scal);
-int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared,
-                       uint32_t slot_h2, G1J* d_pairs);
+int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const uint32_t* d_left_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np,
+                       uint32_t n_shared, G1J* d_pairs);
 }  // namespace h2v
 
 struct h2v_batch {

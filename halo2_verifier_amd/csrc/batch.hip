@@ -19,11 +19,12 @@ template <class T> int dev_alloc(T*& p, size_t count) {
 int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     const Plan& pl = pd->host;
     size_t N = b->max_proofs;
-    size_t sig = (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
+    size_t sig = (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
     if (b->cap_plan_sig == sig && b->pts) return 0;
     int rc;
     uint32_t words = (uint32_t)((pl.stream.size() + 7) / 8);
-    words = (words + 15) / 16 * 16;  // whole 128-byte blocks
+    const uint32_t blockw = pl.opts.transcript == H2V_TRANSCRIPT_KECCAK256 ? 17 : 16;   // 136-byte Keccak / 128-byte Blake2b blocks
+    words = (words + blockw) / blockw * blockw;  // whole blocks, plus room for a final partial one
     b->stream_words = words;
     if ((rc = dev_alloc(b->proofs, N * pl.proof_len))) return rc;
     if ((rc = dev_alloc(b->inst, N * (size_t)pl.n_instance_values * 32))) return rc;
@@ -36,13 +37,13 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->slots, (size_t)pl.n_slots * N))) return rc;
     if ((rc = dev_alloc(b->msm_scal, (N * pl.n_points + pl.n_shared) * 8))) return rc;
     if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
-    if ((rc = dev_alloc(b->left_scal, N * 8))) return rc;
+    if ((rc = dev_alloc(b->left_scal, N * pl.n_points * 8))) return rc;
     if ((rc = dev_alloc(b->acc, 2))) return rc;
     if ((rc = dev_alloc(b->pairs, 2 * N))) return rc;
     if ((rc = dev_alloc(b->ok, N))) return rc;
     if ((rc = dev_alloc(b->out_bytes, 128))) return rc;
     if ((rc = dev_alloc(b->out_ident, 2))) return rc;
-    if ((rc = b->ws.alloc((uint32_t)(N * pl.n_points + pl.n_shared + N), 2))) return rc;
+    if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + pl.n_shared)), 2))) return rc;
     b->cap_plan_sig = sig;
     return 0;
 }
@@ -125,12 +126,13 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
     if (n) { if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, b->mult))) return rc; }
     mark();
+    if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
                b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal};
     if ((rc = frvm_enqueue(s, a))) return rc;
     mark();
     if (single) {
-        if ((rc = single_msm_enqueue(s, b->msm_scal, b->shared, b->pts, n, pl.n_points, pl.n_shared, pl.slot_h2, b->pairs))) return rc;
+        if ((rc = single_msm_enqueue(s, b->msm_scal, b->left_scal, b->shared, b->pts, n, pl.n_points, pl.n_shared, b->pairs))) return rc;
         mark(); mark();
         if ((rc = pairing_check_enqueue(s, ctx->pairing, b->pairs, n, b->ok))) return rc;
         mark();
@@ -139,9 +141,10 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
     if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, b->msm_scal))) return rc; }
     mark();
     uint32_t terms = n ? n * pl.n_points + pl.n_shared : 0;
-    {   // both channels in one set of launches: [0] left = sum_p m_p * h2_p, [1] right = pooled Guard terms + folded VK-wide bases
+    {   // both channels in one set of launches: [0] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points), [1] right = pooled
+        // Guard terms + folded VK-wide bases.  Both index the same point array; unused slots have zero scalars and cost nothing.
         MsmProblems pr; pr.count = 2;
-        pr.p[0] = MsmProblem{b->left_scal, b->pts + pl.slot_h2, b->acc + 0, 8, pl.n_points, n};
+        pr.p[0] = MsmProblem{b->left_scal, b->pts, b->acc + 0, 8, 1, n * pl.n_points};
         pr.p[1] = MsmProblem{b->msm_scal, b->pts, b->acc + 1, 8, 1, terms};
         if ((rc = msm_enqueue_multi(s, b->ws, pr))) return rc;
     }
@@ -205,7 +208,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
     std::vector<uint8_t> flat(n * pl.proof_len, 0), iflat(n * per_inst, 0);
     std::vector<int> forced(n, 0);
     // byte offset where the multi-open part starts: h1 is the first point after all scalars
-    size_t opening_at = pl.point_offsets[pl.slot_h1];
+    size_t opening_at = pl.opening_offset;
     for (size_t i = 0; i < n; ++i) {
         if (!proofs[i]) { set_last_error("null proof pointer"); return H2V_ERR_BAD_ARGUMENT; }
         if (proof_lens[i] < pl.proof_len) {
@@ -374,7 +377,10 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len, const ui
     const Plan& pl = b->plan->host;
     size_t T = pl.right_term_order.size();
     do {
-        if (T > *n_right || 1 > *n_left) { set_last_error("h2v_guard_msm: output capacity too small"); rc = H2V_ERR_BAD_ARGUMENT; break; }
+        size_t TL = pl.left_term_order.size();
+        if (T > *n_right || TL > *n_left) { set_last_error("h2v_guard_msm: output capacity too small"); rc = H2V_ERR_BAD_ARGUMENT; break; }
+        std::vector<uint32_t> lscal((size_t)pl.n_points * 8);
+        if (hipMemcpy(lscal.data(), b->left_scal, lscal.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
         std::vector<uint32_t> scal((size_t)pl.n_points * 8);
         std::vector<Fr> shared(pl.n_shared);
         std::vector<G1A> pts(pl.n_points + pl.n_shared);
@@ -388,9 +394,12 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len, const ui
             else { memcpy(right_scalars32 + 32 * t, &scal[(size_t)w.second * 8], 32); put_pt(pts[w.second], right_bases64 + 64 * t); }
         }
         *n_right = T;
-        memset(left_scalars32, 0, 32); left_scalars32[0] = 1;
-        put_pt(pts[pl.slot_h2], left_bases64);
-        *n_left = 1;
+        for (size_t t = 0; t < TL; ++t) {
+            uint32_t slot = pl.left_term_order[t].second;
+            memcpy(left_scalars32 + 32 * t, &lscal[(size_t)slot * 8], 32);
+            put_pt(pts[slot], left_bases64 + 64 * t);
+        }
+        *n_left = TL;
         if (challenges32 && n_challenges) {
             // reorder squeeze order -> [user challenges.., theta, beta, gamma, y, x, y', v, u]
             size_t nc = pl.n_challenges;
@@ -400,7 +409,7 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len, const ui
             std::vector<uint32_t> order;
             uint8_t max_phase = 0; for (uint8_t p2 : vk.advice_column_phase) max_phase = std::max(max_phase, p2);
             for (unsigned ph = 0; ph <= max_phase; ++ph) for (uint32_t i = 0; i < vk.num_challenges; ++i) if (vk.challenge_phase[i] == ph) order.push_back(i);
-            for (uint32_t i = 0; i < 8; ++i) order.push_back(vk.num_challenges + i);
+            for (uint32_t i = 0; i + vk.num_challenges < nc; ++i) order.push_back(vk.num_challenges + i);
             for (size_t q = 0; q < order.size() && q < chal.size(); ++q) chal[q].to_bytes(challenges32 + 32 * order[q]);
             *n_challenges = nc;
         }

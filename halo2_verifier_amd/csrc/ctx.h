@@ -14,6 +14,7 @@ struct h2v_ctx {
     hipStream_t stream = nullptr;  // used by the synchronous single-shot entry points
     std::mutex mu;                 // serialises the single-shot entry points
     h2v::VkDevice* vk = nullptr;   // per-VK compiled program and constants (vkplan.hip)
+    int multiopen = 0, transcript = 0;  // h2v_options
 };
 
 namespace h2v {

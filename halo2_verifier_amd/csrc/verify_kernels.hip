@@ -154,6 +154,87 @@ __global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __r
     }
 }
 
+// ------------------------------------------------------------------ legacy Keccak-256 transcript (transcript/mod.rs:234-272)
+__device__ __forceinline__ unsigned long long rotl64(unsigned long long x, int c) { return c ? (x << c) | (x >> (64 - c)) : x; }
+__constant__ unsigned long long KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+    0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+__device__ __noinline__ void keccak_f1600(unsigned long long a[25]) {
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    for (int r = 0; r < 24; ++r) {
+        unsigned long long c[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            unsigned long long d = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+            for (int y = 0; y < 5; ++y) a[x + 5 * y] ^= d;
+        }
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(a[x + 5 * y], ROT[x + 5 * y]);
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= KECCAK_RC[r];
+    }
+}
+// digest of  stream[0..len) | suffix  given the running state `st` that has absorbed the first `blk` full 136-byte blocks
+__device__ __forceinline__ void keccak_tail(const unsigned long long st[25], const unsigned long long* __restrict__ words, uint32_t n, uint32_t p, uint32_t blk,
+                                            uint32_t len, uint32_t suffix, unsigned long long out[4]) {
+    unsigned long long a[25];
+    for (int i = 0; i < 25; ++i) a[i] = st[i];
+    uint32_t rem = len - blk * 136;  // 0..135 bytes of the stream remain, then the suffix byte, then the padding
+    for (int j = 0; j < 17; ++j) {
+        unsigned long long w = 0;
+        uint32_t lo = 8 * j;
+        if (lo < rem) {
+            w = words[((size_t)blk * 17 + j) * n + p];
+            if (lo + 8 > rem) w &= (1ULL << (8 * (rem - lo))) - 1;
+        }
+        if (rem >= lo && rem < lo + 8) w |= (unsigned long long)suffix << (8 * (rem - lo));
+        a[j] ^= w;
+    }
+    uint32_t pad_at = rem + 1;  // first padding byte
+    if (pad_at == 136) {        // the suffix filled the block: the padding gets a block of its own
+        keccak_f1600(a);
+        a[0] ^= 0x01ULL; a[16] ^= 0x8000000000000000ULL;
+    } else {
+        a[pad_at / 8] ^= 0x01ULL << (8 * (pad_at % 8));
+        a[16] ^= 0x8000000000000000ULL;
+    }
+    keccak_f1600(a);
+    for (int i = 0; i < 4; ++i) out[i] = a[i];
+}
+// stream words are laid out in 136-byte blocks here: word (blk * 17 + j)
+__global__ void __launch_bounds__(64) k_transcript_keccak(const unsigned long long* __restrict__ words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
+                                                          uint32_t n, Fr* __restrict__ chal) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    unsigned long long st[25];
+    for (int i = 0; i < 25; ++i) st[i] = 0;
+    uint32_t blk = 0;
+    for (uint32_t q = 0; q < n_squeeze; ++q) {
+        uint32_t len = squeeze_at[q];
+        uint32_t full = len / 136;
+        for (; blk < full; ++blk) {
+            for (int j = 0; j < 17; ++j) st[j] ^= words[((size_t)blk * 17 + j) * n + p];
+            keccak_f1600(st);
+        }
+        unsigned long long lo[4], hi[4];
+        keccak_tail(st, words, n, p, blk, len, 10, lo);   // KECCAK256_PREFIX_CHALLENGE_LO
+        keccak_tail(st, words, n, p, blk, len, 11, hi);   // KECCAK256_PREFIX_CHALLENGE_HI
+        uint32_t w32[16];
+        for (int i = 0; i < 4; ++i) { w32[2 * i] = (uint32_t)lo[i]; w32[2 * i + 1] = (uint32_t)(lo[i] >> 32); w32[8 + 2 * i] = (uint32_t)hi[i]; w32[8 + 2 * i + 1] = (uint32_t)(hi[i] >> 32); }
+        chal[(size_t)q * n + p] = Fr::from_uniform_words(w32);
+    }
+}
+
 // mult[p] = prod_{j > first+p} r_j over the tail of draws; tail[0] is the draw of this shard's proof 0.
 __global__ void __launch_bounds__(1024) k_multipliers(const uint8_t* __restrict__ tail, uint32_t n_tail, uint32_t n, Fr* __restrict__ mult) {
     __shared__ Fr part[1024];
@@ -254,7 +335,7 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
                 uint32_t raw[8];
                 slot_load(a.slots, in.a, n, p).to_raw(raw);
                 bool bad = a.status[p] != 0;
-                uint32_t* dst = a.left_scal + (size_t)p * 8;
+                uint32_t* dst = a.left_scal + ((size_t)p * a.np + in.b) * 8;
                 for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
             }
@@ -282,9 +363,9 @@ __global__ void __launch_bounds__(256) k_fold_shared(const Fr* __restrict__ shar
     }
 }
 
-// SingleStrategy: each proof's own two channels (left = h2, right = its full Guard MSM), no pooling.
-__global__ void __launch_bounds__(64) k_single_msm(const uint32_t* __restrict__ msm_scal, const Fr* __restrict__ shared, const G1A* __restrict__ pts,
-                                                   uint32_t n, uint32_t np, uint32_t n_shared, uint32_t slot_h2, G1J* __restrict__ pairs) {
+// SingleStrategy: each proof's own two channels (left = sum left_scal * own points, right = its full Guard MSM), no pooling.
+__global__ void __launch_bounds__(64) k_single_msm(const uint32_t* __restrict__ msm_scal, const uint32_t* __restrict__ left_scal, const Fr* __restrict__ shared,
+                                                   const G1A* __restrict__ pts, uint32_t n, uint32_t np, uint32_t n_shared, G1J* __restrict__ pairs) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const G1A* shared_bases = pts + (size_t)n * np;
@@ -307,7 +388,21 @@ __global__ void __launch_bounds__(64) k_single_msm(const uint32_t* __restrict__ 
         }
         acc = g1_add(acc, t);
     }
-    pairs[2 * (size_t)p] = G1J::from_affine(pts[(size_t)p * np + slot_h2]);
+    // left channel: the few slots with a non-zero left scalar (h2 for SHPLONK, the witness points for GWC)
+    G1J left = G1J::identity();
+    for (uint32_t s = 0; s < np; ++s) {
+        const uint32_t* k = left_scal + ((size_t)p * np + s) * 8;
+        uint32_t nz = 0;
+        for (int i = 0; i < 8; ++i) nz |= k[i];
+        if (!nz) continue;
+        G1J t = G1J::identity();
+        for (int bit = 253; bit >= 0; --bit) {
+            t = g1_dbl(t);
+            if ((k[bit >> 5] >> (bit & 31)) & 1) t = g1_add_affine(t, pts[(size_t)p * np + s]);
+        }
+        left = g1_add(left, t);
+    }
+    pairs[2 * (size_t)p] = left;
     pairs[2 * (size_t)p + 1] = acc;
 }
 
@@ -331,7 +426,10 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
     uint32_t stream_len = (uint32_t)pl.stream.size();
     uint32_t n_words = g.stream_words;
     hipLaunchKernelGGL(k_stream_build, dim3((n + 255) / 256, n_words), dim3(256), 0, s, g.pd->stream, stream_len, g.proofs, pl.proof_len, g.ycanon, pl.n_points, g.inst, pl.n_instance_values, n, g.words);
-    hipLaunchKernelGGL(k_transcript, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
+    if (pl.opts.transcript == H2V_TRANSCRIPT_KECCAK256)
+        hipLaunchKernelGGL(k_transcript_keccak, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
+    else
+        hipLaunchKernelGGL(k_transcript, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -352,9 +450,9 @@ int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t 
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t slot_h2, G1J* d_pairs) {
+int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const uint32_t* d_left_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared, G1J* d_pairs) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_single_msm, dim3((n + 63) / 64), dim3(64), 0, s, d_msm_scal, d_shared, d_pts, n, np, n_shared, slot_h2, d_pairs);
+    hipLaunchKernelGGL(k_single_msm, dim3((n + 63) / 64), dim3(64), 0, s, d_msm_scal, d_left_scal, d_shared, d_pts, n, np, n_shared, d_pairs);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

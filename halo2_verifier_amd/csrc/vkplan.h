@@ -58,7 +58,7 @@ enum VmOp : uint32_t {
     OP_LOAD_MULT = 12,    // d <- batch multiplier of this proof
     OP_STORE_MSM = 13,    // msm_scalars[proof][point slot b] <- canonical(a)
     OP_STORE_SHARED = 14, // shared[proof][b] <- a (Montgomery)
-    OP_STORE_LEFT = 15,   // left_scalars[proof] <- canonical(a)
+    OP_STORE_LEFT = 15,   // left_scalars[proof][point slot b] <- canonical(a)
 };
 struct VmInstr { uint32_t op, d, a, b; };
 
@@ -67,12 +67,17 @@ struct TranscriptSrc {  // one byte of the absorbed stream
     uint8_t kind; uint8_t value; uint32_t offset;
 };
 
+struct PlanOptions { int multiopen = 0; int transcript = 0; };  // h2v_options
+
 struct Plan {
+    PlanOptions opts;
     // proof layout
     uint32_t n_points = 0, n_scalars = 0, proof_len = 0;
     std::vector<uint32_t> point_offsets, scalar_offsets;  // byte offsets into the proof
     uint32_t n_main_points = 0;                           // points read before the multi-open part (errors there are Transcript, after: Opening)
-    uint32_t slot_h1 = 0, slot_h2 = 0;
+    uint32_t slot_h1 = 0, slot_h2 = 0;                    // SHPLONK only
+    uint32_t opening_offset = 0;                          // byte offset of the first point of the multi-open part
+    std::vector<std::pair<uint8_t, uint32_t>> left_term_order;  // reference order of the left channel's terms
     // transcript
     std::vector<TranscriptSrc> stream;     // absorbed byte stream incl. the 0x00 challenge markers
     std::vector<uint32_t> squeeze_at;      // stream length at which challenge i is squeezed
@@ -92,7 +97,7 @@ struct Plan {
     uint32_t n_instance_values = 0;
 };
 // Returns 0 or an H2V error code (InstanceTooLarge, ReferencePanic for an empty gate polynomial, ...)
-int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, Plan& out, std::string& err);
+int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, PlanOptions opts, Plan& out, std::string& err);
 
 struct PlanDevice {
     Plan host;

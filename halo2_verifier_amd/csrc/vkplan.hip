@@ -193,7 +193,7 @@ struct Builder {
     Val load_mult() { if (mult_node == (Val)-1) mult_node = push(OP_LOAD_MULT, 0, 0, 0, true); return mult_node; }
     void store_msm(Val a, uint32_t slot) { push(OP_STORE_MSM, a, 0, slot, false); }
     void store_shared(Val a, uint32_t j) { push(OP_STORE_SHARED, a, 0, j, false); }
-    void store_left(Val a) { push(OP_STORE_LEFT, a, 0, 0, false); }
+    void store_left(Val a, uint32_t slot) { push(OP_STORE_LEFT, a, 0, slot, false); }
 
     // values[i] <- 1 / values[i] for all i with ONE inversion (Montgomery's trick)
     void batch_invert(std::vector<Val>& vals) {
@@ -260,7 +260,10 @@ struct SymQuery { CommitRef c; int64_t rot; Val eval; };  // point = x * omega^r
 }  // namespace
 
 // =============================================================================== plan compiler
-int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, Plan& plan, std::string& err) {
+int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, PlanOptions opts, Plan& plan, std::string& err) {
+    plan.opts = opts;
+    const bool gwc = opts.multiopen == H2V_MULTIOPEN_GWC;
+    if (opts.multiopen < 0 || opts.multiopen > 1 || opts.transcript < 0 || opts.transcript > 1) { err = "unknown multiopen / transcript option"; return H2V_ERR_BAD_ARGUMENT; }
     if (col_lens.size() != vk.num_instance_columns) { err = "instances do not match the VK's instance column count"; return H2V_ERR_INVALID_INSTANCES; }
     if (params.k != vk.k) { err = "params.k differs from vk.k"; return H2V_ERR_BAD_ARGUMENT; }
     const uint64_t n = 1ULL << vk.k;
@@ -329,8 +332,12 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         plan.squeeze_at.push_back((uint32_t)plan.stream.size());
         squeeze_order.push_back(chal_id);
     };
-    const uint32_t C_THETA = (uint32_t)Ch, C_BETA = C_THETA + 1, C_GAMMA = C_THETA + 2, C_Y = C_THETA + 3, C_X = C_THETA + 4, C_SY = C_THETA + 5, C_SV = C_THETA + 6, C_SU = C_THETA + 7;
+    // SHPLONK squeezes y', v, u (shplonk.rs:195-199); GWC squeezes v, u (gwc.rs:73-83)
+    const uint32_t C_THETA = (uint32_t)Ch, C_BETA = C_THETA + 1, C_GAMMA = C_THETA + 2, C_Y = C_THETA + 3, C_X = C_THETA + 4;
+    const uint32_t C_SY = C_THETA + 5, C_SV = gwc ? C_THETA + 5 : C_THETA + 6, C_SU = C_SV + 1;
     plan.n_user_challenges = (uint32_t)Ch; plan.n_challenges = C_SU + 1;
+    if (opts.transcript == H2V_TRANSCRIPT_KECCAK256)   // Keccak256Read::init absorbs the label (transcript/mod.rs:143-145)
+        for (const char* c = "Halo2-Transcript"; *c; ++c) emit_const((uint8_t)*c);
     {   // vk.hash_into + instances (plonk/vk.rs:145-152, lib.rs:76-82)
         uint8_t repr[32]; vk.transcript_repr.to_bytes(repr);
         emit_const(2);
@@ -371,10 +378,28 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     std::vector<SS> s_sh(Sh);
     for (auto& s : s_sh) { s.product = absorb_scalar(); s.product_next = absorb_scalar(); }
     plan.n_main_points = np;
-    squeeze(C_SY); squeeze(C_SV);
-    plan.slot_h1 = absorb_point();
-    squeeze(C_SU);
-    plan.slot_h2 = absorb_point();
+    plan.opening_offset = off;
+    // distinct opening points in first-appearance order of the query list (lib.rs:349-414) — GWC reads one witness
+    // point per distinct point (gwc.rs:138-163); computed here because the number of points it reads depends on it
+    std::vector<int64_t> gwc_points;
+    std::vector<uint32_t> gwc_w_slot;
+    if (gwc) {
+        auto seen = [&](int64_t r) { int64_t k2 = norm_rot(r); for (int64_t e : gwc_points) if (e == k2) return; gwc_points.push_back(k2); };
+        for (const QueryH& q : vk.advice_queries) seen(q.rotation);
+        if (nsets) { seen(0); seen(1); if (nsets > 1) seen(-(int64_t)(bf + 1)); }
+        if (L) { seen(0); seen(-1); seen(1); }
+        if (Sh) { seen(0); seen(1); }
+        for (const QueryH& q : vk.fixed_queries) seen(q.rotation);
+        seen(0);
+        squeeze(C_SV);
+        for (size_t i = 0; i < gwc_points.size(); ++i) gwc_w_slot.push_back(absorb_point());
+        squeeze(C_SU);
+    } else {
+        squeeze(C_SY); squeeze(C_SV);
+        plan.slot_h1 = absorb_point();
+        squeeze(C_SU);
+        plan.slot_h2 = absorb_point();
+    }
     plan.n_points = np; plan.n_scalars = nsc; plan.proof_len = off;
     // challenge id -> position in squeeze order
     std::vector<uint32_t> sq_of(plan.n_challenges, 0);
@@ -385,7 +410,8 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     auto chal = [&](uint32_t id) { return b.load_chal(sq_of[id]); };
     std::vector<Val> user_ch(Ch);
     for (size_t i = 0; i < Ch; ++i) user_ch[i] = chal((uint32_t)i);
-    Val theta = chal(C_THETA), beta = chal(C_BETA), gamma = chal(C_GAMMA), y = chal(C_Y), x = chal(C_X), sy = chal(C_SY), sv = chal(C_SV), su = chal(C_SU);
+    Val theta = chal(C_THETA), beta = chal(C_BETA), gamma = chal(C_GAMMA), y = chal(C_Y), x = chal(C_X), sv = chal(C_SV), su = chal(C_SU);
+    Val sy = gwc ? sv : chal(C_SY);
     Val xn = b.sqrn(x, vk.k);  // x^n, n = 2^k   (lib.rs:180,259)
     Val xn_m1 = b.sub(xn, b.one());
 
@@ -469,8 +495,9 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     std::map<int64_t, Val> point_of;  // x * omega^rot for the opening points
     for (int64_t r : super) point_of[r] = b.mul(x, b.cst(omega_pow(r)));
     Val z_diff_0 = b.one();
-    for (int64_t r : super) if (std::find(rsets[0].rots.begin(), rsets[0].rots.end(), r) == rsets[0].rots.end()) z_diff_0 = b.mul(b.sub(su, point_of[r]), z_diff_0);
-    std::vector<Val> inv_list = {xn_m1, x, z_diff_0};
+    if (!gwc) for (int64_t r : super) if (std::find(rsets[0].rots.begin(), rsets[0].rots.end(), r) == rsets[0].rots.end()) z_diff_0 = b.mul(b.sub(su, point_of[r]), z_diff_0);
+    // GWC needs neither 1/x nor 1/z_diff_0; keeping two harmless entries keeps the indices below fixed
+    std::vector<Val> inv_list = {xn_m1, gwc ? b.one() : x, gwc ? b.one() : z_diff_0};
     for (int64_t r : l_rots) inv_list.push_back(b.sub(x, b.cst(omega_pow(r))));
     b.batch_invert(inv_list);
     Val xn_m1_inv = inv_list[0], x_inv = inv_list[1], z_0_diff_inverse = inv_list[2];
@@ -609,10 +636,48 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         }
     };
     auto assign = [&](std::pair<uint8_t, uint32_t> where, Val v) {
-        plan.right_term_order.push_back(where);
         Val& dst = where.first ? shared_scalar[where.second] : msm_scalar[where.second];
-        dst = dst == (Val)-1 ? v : b.add(dst, v);  // a commitment appears in exactly one rotation set; the add is for safety only
+        // SHPLONK: a commitment belongs to exactly one rotation set; GWC: a commitment opened at several points occurs once
+        // per point — its scalars are summed and it is reported once (first appearance) in the Guard
+        if (dst == (Val)-1) { plan.right_term_order.push_back(where); dst = v; }
+        else dst = b.add(dst, v);
     };
+    std::vector<Val> left_scalar(np, (Val)-1);
+    if (gwc) {
+        // gwc.rs:86-132: point group i has weight u^i, query j inside it weight v^j
+        std::vector<std::vector<const SymQuery*>> groups(gwc_points.size());
+        for (const SymQuery& q : queries) {
+            size_t gi = std::find(gwc_points.begin(), gwc_points.end(), q.rot) - gwc_points.begin();
+            if (gi >= groups.size()) { err = "internal: opening point missing from the GWC point list"; return H2V_ERR_BAD_ARGUMENT; }
+            groups[gi].push_back(&q);
+        }
+        // reference term order of the right channel: witness_with_aux, commitment_multi, (eval_multi, -g)
+        Val power_of_u = b.one();
+        std::vector<Val> pu(groups.size());
+        for (size_t i = 0; i < groups.size(); ++i) { pu[i] = power_of_u; power_of_u = b.mul(su, power_of_u); }
+        for (size_t i = 0; i < groups.size(); ++i) {
+            assign({0, gwc_w_slot[i]}, b.mul(pu[i], point_of[gwc_points[i]]));
+            left_scalar[gwc_w_slot[i]] = pu[i];
+            plan.left_term_order.push_back({0, gwc_w_slot[i]});
+        }
+        Val eval_multi = b.zero();
+        for (size_t i = 0; i < groups.size(); ++i) {
+            Val power_of_v = b.one(), eval_batch = b.zero();
+            for (const SymQuery* q : groups[i]) {
+                Val w = b.mul(power_of_v, pu[i]);
+                if (q->c.kind == K_H_MSM) {
+                    std::vector<Val> xnp(H); if (H) xnp[0] = b.one();
+                    for (size_t t = 1; t < H; ++t) xnp[t] = b.mul(xnp[t - 1], xn);
+                    for (size_t t = H; t-- > 0;) assign({0, h_slot[t]}, b.mul(w, xnp[t]));
+                } else assign(slot_of(q->c), w);
+                eval_batch = b.add(eval_batch, b.mul(power_of_v, q->eval));
+                power_of_v = b.mul(sv, power_of_v);
+            }
+            eval_multi = b.add(eval_multi, b.mul(pu[i], eval_batch));
+        }
+        plan.shared_bases.back().y = plan.shared_bases.back().y.neg();  // the last VK-wide base is -g for GWC (gwc.rs:130-131)
+        assign({1, (uint32_t)(F + P)}, eval_multi);
+    } else {
     Val z_0 = b.one();
     for (int64_t r : rsets[0].rots) z_0 = b.mul(b.sub(su, point_of[r]), z_0);
     Val r_outer = b.zero();
@@ -671,10 +736,13 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     assign({1, (uint32_t)(F + P)}, b.neg(r_outer));
     assign({0, plan.slot_h1}, b.neg(z_0));
     assign({0, plan.slot_h2}, su);
+    left_scalar[plan.slot_h2] = b.one();   // left channel: (1, h2) per proof (shplonk.rs:262)
+    plan.left_term_order.push_back({0, plan.slot_h2});
+    }
     // stores, scaled by the proof's batch multiplier (kzg/strategy.rs:129, msm.rs:173-176)
     for (uint32_t s2 = 0; s2 < np; ++s2) b.store_msm(msm_scalar[s2] == (Val)-1 ? b.zero() : b.mul(msm_scalar[s2], mult), s2);
     for (uint32_t j = 0; j < plan.n_shared; ++j) b.store_shared(shared_scalar[j] == (Val)-1 ? b.zero() : b.mul(shared_scalar[j], mult), j);
-    b.store_left(mult);  // left channel: (1, h2) per proof (shplonk.rs:262)
+    for (uint32_t s2 = 0; s2 < np; ++s2) if (left_scalar[s2] != (Val)-1) b.store_left(b.mul(left_scalar[s2], mult), s2);
 
     b.emit(plan.code, plan.n_slots);
     plan.consts = b.consts;
@@ -726,7 +794,8 @@ int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice**
     if (it != ctx->vk->plans.end()) { *out = it->second; return 0; }
     PlanDevice* pd = new PlanDevice();
     std::string err;
-    int rc = compile_plan(ctx->vk->vk, ctx->params, col_lens, pd->host, err);
+    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript;
+    int rc = compile_plan(ctx->vk->vk, ctx->params, col_lens, po, pd->host, err);
     if (rc) { set_last_error("plan: " + err); delete pd; return rc; }
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     rc = pd->upload();

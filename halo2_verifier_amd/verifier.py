@@ -31,6 +31,20 @@ class PlonkError(enum.IntEnum):  # plonk/mod.rs:19-32 (+ the reference's panics 
     ReferencePanic = -7
 
 
+class MultiOpen(enum.IntEnum):  # the `V: Verifier` parameter of verify_proof (lib.rs:35): VerifierSHPLONK / VerifierGWC
+    SHPLONK = 0
+    GWC = 1
+
+
+class TranscriptKind(enum.IntEnum):  # the `T: TranscriptRead` parameter (lib.rs:37): Blake2bRead / Keccak256Read
+    Blake2b = 0
+    Keccak256 = 1
+
+
+class _Options(ctypes.Structure):
+    _fields_ = [("multiopen", ctypes.c_int), ("transcript", ctypes.c_int)]
+
+
 class ParamsKZG:
     """Verifier-side KZG parameters: k, g, g2, s_g2 (poly/kzg/commitment.rs:22-29) as bytes."""
 
@@ -79,12 +93,14 @@ def _flatten_instances(instances):
 class Context:
     """ParamsKZG + VerifyingKey resident on one GPU (h2v_ctx)."""
 
-    def __init__(self, params: ParamsKZG, vk: VerifyingKey = None, device: int = 0):
+    def __init__(self, params: ParamsKZG, vk: VerifyingKey = None, device: int = 0, multiopen=MultiOpen.SHPLONK,
+                 transcript=TranscriptKind.Blake2b):
         self._lib = _lib.load_library()
         self._h = ctypes.c_void_p()
         vkb = vk.data if vk is not None else None
-        check(self._lib.h2v_ctx_create(params.data, len(params.data), int(params.format), vkb, len(vkb) if vkb else 0,
-                                       int(vk.format) if vk is not None else 0, device, ctypes.byref(self._h)))
+        opts = _Options(int(multiopen), int(transcript))
+        check(self._lib.h2v_ctx_create_ex(params.data, len(params.data), int(params.format), vkb, len(vkb) if vkb else 0,
+                                          int(vk.format) if vk is not None else 0, device, ctypes.byref(opts), ctypes.byref(self._h)))
         self.params, self.vk, self.device = params, vk, device
 
     def close(self):
@@ -174,9 +190,9 @@ class Context:
         f, lens = _flatten_instances(instances)
         cl = (ctypes.c_size_t * max(len(lens), 1))(*lens)
         rs, rb = ctypes.create_string_buffer(32 * cap), ctypes.create_string_buffer(64 * cap)
-        ls, lb = ctypes.create_string_buffer(32 * 16), ctypes.create_string_buffer(64 * 16)
+        ls, lb = ctypes.create_string_buffer(32 * 64), ctypes.create_string_buffer(64 * 64)
         ch = ctypes.create_string_buffer(32 * 64)
-        nr, nl, nc = ctypes.c_size_t(cap), ctypes.c_size_t(16), ctypes.c_size_t(64)
+        nr, nl, nc = ctypes.c_size_t(cap), ctypes.c_size_t(64), ctypes.c_size_t(64)
         rc = self._lib.h2v_guard_msm(self._h, proof, len(proof), f, len(lens), cl, rs, rb, ctypes.byref(nr), ls, lb, ctypes.byref(nl), ch, ctypes.byref(nc))
         if rc != 0:
             return rc, None

@@ -65,6 +65,18 @@ const char* h2v_last_error(void);
 int h2v_ctx_create(const uint8_t* params, size_t params_len, int params_format,
                    const uint8_t* vk, size_t vk_len, int vk_format,
                    int device, h2v_ctx** out);
+/* The two generic parameters of the reference's verify_proof that change what is computed (lib.rs:33-40):
+ *   multiopen:  0 = VerifierSHPLONK (poly/kzg/multiopen/shplonk.rs), 1 = VerifierGWC (poly/kzg/multiopen/gwc.rs)
+ *   transcript: 0 = Blake2bRead, 1 = Keccak256Read (transcript/mod.rs:104-116)
+ * h2v_ctx_create == h2v_ctx_create_ex with {0, 0}. */
+typedef struct h2v_options { int multiopen; int transcript; } h2v_options;
+#define H2V_MULTIOPEN_SHPLONK 0
+#define H2V_MULTIOPEN_GWC 1
+#define H2V_TRANSCRIPT_BLAKE2B 0
+#define H2V_TRANSCRIPT_KECCAK256 1
+int h2v_ctx_create_ex(const uint8_t* params, size_t params_len, int params_format,
+                      const uint8_t* vk, size_t vk_len, int vk_format,
+                      int device, const h2v_options* options, h2v_ctx** out);
 void h2v_ctx_destroy(h2v_ctx* ctx);
 
 /* Shape of one proof for this VK (Np points, Ns scalars, T_R right-channel terms). */
@@ -108,8 +120,9 @@ int h2v_verify_each(h2v_ctx* ctx, size_t n,
                     const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens,
                     int* per_proof_status);
 
-/* Debug / parity: the Guard of one proof in reference term order (shplonk.rs:256-264), and the
- * Fiat-Shamir challenges [user challenges.., theta, beta, gamma, y, x, y', v, u].
+/* Debug / parity: the Guard of one proof in reference term order (shplonk.rs:256-264; gwc.rs:126-132, where a
+ * commitment opened at several points is reported once, with its scalars summed), and the
+ * Fiat-Shamir challenges [user challenges.., theta, beta, gamma, y, x, y', v, u] (GWC: [.., x, v, u]).
  * On entry *n_right / *n_left / *n_challenges hold the capacities (in elements). */
 int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len,
                   const uint8_t* instances32, size_t n_instance_columns, const size_t* col_lens,

@@ -30,6 +30,7 @@ std::vector<std::vector<Fr>> parse_instances(const uint8_t* inst32, const size_t
     return out;
 }
 struct Setup {
+    int multiopen = 0, transcript = 0;   // options of the prover side (h2o_setup_set_options)
     CommitKey ck;
     ProvingKey pk;
     int kind;  // 0 vector_mul, 1 two-phase shuffle, 2 wide
@@ -42,9 +43,12 @@ size_t copy_out(const std::vector<uint8_t>& v, uint8_t* buf, size_t cap) {
 }
 }  // namespace
 
+static thread_local VerifyOptions g_opts;
+
 extern "C" {
 
 // ---------------------------------------------------------------- primitives
+int h2o_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) { Keccak256 k; k.update(data, len); k.finalize(out); return 0; }
 int h2o_fr_from_uniform(const uint8_t in[64], uint8_t out[32]) { Fr::from_uniform_bytes(in).to_bytes(out); return 0; }
 int h2o_blake2b_personal(const uint8_t personal[16], const uint8_t* data, size_t len, uint8_t out[64]) {
     Blake2b h((const char*)personal); h.update(data, len); h.finalize(out); return 0;
@@ -92,7 +96,7 @@ int h2o_verify_single(const uint8_t* params, size_t plen, int pfmt, const uint8_
     try {
         ParamsKZG p = read_params(params, plen, (SerdeFormat)pfmt);
         VerifyingKey vk = read_vk(vkb, vlen, (SerdeFormat)vfmt);
-        return verify_single(p, vk, parse_instances(inst32, col_lens, ncols), proof, proof_len);
+        return verify_single(p, vk, parse_instances(inst32, col_lens, ncols), proof, proof_len, g_opts);
     } catch (...) { return -100; }
 }
 
@@ -107,7 +111,7 @@ int h2o_guard_msm(const uint8_t* params, size_t plen, int pfmt, const uint8_t* v
         ParamsKZG p = read_params(params, plen, (SerdeFormat)pfmt);
         VerifyingKey vk = read_vk(vkb, vlen, (SerdeFormat)vfmt);
         DualMSM acc; VerifyTrace t;
-        Error e = verify_proof(p, vk, parse_instances(inst32, col_lens, ncols), proof, proof_len, acc, &t);
+        Error e = verify_proof(p, vk, parse_instances(inst32, col_lens, ncols), proof, proof_len, acc, &t, nullptr, g_opts);
         if (e != OK) return e;
         size_t cap_r = *n_right, cap_l = *n_left;
         *n_right = acc.right.scalars.size(); *n_left = acc.left.scalars.size();
@@ -116,7 +120,9 @@ int h2o_guard_msm(const uint8_t* params, size_t plen, int pfmt, const uint8_t* v
         for (size_t i = 0; i < *n_left; ++i) { acc.left.scalars[i].to_bytes(left_scalars32 + 32 * i); g1_to_xy(acc.left.bases[i].to_affine(), left_bases64 + 64 * i); }
         if (challenges32) {
             std::vector<Fr> ch = t.challenges;
-            for (const Fr& f : {t.theta, t.beta, t.gamma, t.y, t.x, t.sh_y, t.sh_v, t.sh_u}) ch.push_back(f);
+            for (const Fr& f : {t.theta, t.beta, t.gamma, t.y, t.x}) ch.push_back(f);
+            if (g_opts.multiopen == MO_SHPLONK) ch.push_back(t.sh_y);   // GWC has no y' (gwc.rs:73-83: v, then u)
+            ch.push_back(t.sh_v); ch.push_back(t.sh_u);
             if (ch.size() > *n_challenges) return -101;
             *n_challenges = ch.size();
             for (size_t i = 0; i < ch.size(); ++i) ch[i].to_bytes(challenges32 + 32 * i);
@@ -139,7 +145,7 @@ int h2o_verify_batch(const uint8_t* params, size_t plen, int pfmt, const uint8_t
         for (size_t i = 0; i < n; ++i) {
             Fr r; if (!Fr::from_bytes(rand32 + 32 * i, r)) return -1;
             DualMSM saved = st.acc;
-            Error e = st.process(p, vk, parse_instances(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, r);
+            Error e = st.process(p, vk, parse_instances(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, r, g_opts);
             statuses[i] = e;
             if (e != OK) { all_ok = false; saved.scale(r); st.acc = saved; }
         }
@@ -159,7 +165,7 @@ int h2o_verify_each(const uint8_t* params, size_t plen, int pfmt, const uint8_t*
         size_t per = 0; for (size_t c = 0; c < ncols; ++c) per += col_lens[c];
         int acc = 0;
         for (size_t i = 0; i < n; ++i) {
-            statuses[i] = verify_single(p, vk, parse_instances(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len);
+            statuses[i] = verify_single(p, vk, parse_instances(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, g_opts);
             acc += statuses[i] == OK;
         }
         return acc;
@@ -186,6 +192,9 @@ void* h2o_setup_wide(uint32_t k, size_t A, size_t F, size_t L, size_t Sh, uint32
     try { Setup* s = make_setup(circuit_wide(k, A, F, L, Sh, deg, seed), srs, srs_len, s_seed); if (s) { s->kind = 2; s->wide_seed = seed; } return s; } catch (...) { return nullptr; }
 }
 void h2o_setup_free(void* h) { delete (Setup*)h; }
+void h2o_setup_set_options(void* h, int multiopen, int transcript) { ((Setup*)h)->multiopen = multiopen; ((Setup*)h)->transcript = transcript; }
+// verifier-side options for every h2o_verify_* / h2o_guard_msm call of this thread (0/0 = SHPLONK + Blake2b)
+void h2o_set_verify_options(int multiopen, int transcript) { g_opts.multiopen = multiopen; g_opts.transcript = transcript; }
 size_t h2o_setup_vk(void* h, int fmt, uint8_t* buf, size_t cap) { return copy_out(write_vk(((Setup*)h)->pk.vk, (SerdeFormat)fmt), buf, cap); }
 size_t h2o_setup_params(void* h, int fmt, uint8_t* buf, size_t cap) { return copy_out(write_params(((Setup*)h)->ck.params, (SerdeFormat)fmt), buf, cap); }
 
@@ -195,7 +204,7 @@ size_t h2o_prove_vector_mul(void* h, const uint8_t* a32, const uint8_t* b32, uin
     std::vector<Fr> a(s->n_mul), b(s->n_mul), c(s->n_mul);
     for (size_t i = 0; i < s->n_mul; ++i) { Fr::from_bytes(a32 + 32 * i, a[i]); Fr::from_bytes(b32 + 32 * i, b[i]); c[i] = a[i] * b[i]; if (instances_out) c[i].to_bytes(instances_out + 32 * i); }
     Rng rng(rng_seed);
-    return copy_out(create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng), proof, cap);
+    return copy_out(create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng, s->multiopen, s->transcript), proof, cap);
 }
 // batch of `count` distinct proofs with pseudo-random a, b derived from seed+i; nthreads workers
 size_t h2o_prove_vector_mul_batch(void* h, size_t count, uint64_t seed, unsigned nthreads, uint8_t* proofs, size_t proof_len, uint8_t* instances_out) {
@@ -208,7 +217,7 @@ size_t h2o_prove_vector_mul_batch(void* h, size_t count, uint64_t seed, unsigned
             std::vector<Fr> a(s->n_mul), b(s->n_mul), c(s->n_mul);
             for (size_t j = 0; j < s->n_mul; ++j) { a[j] = wr.fr(); b[j] = wr.fr(); c[j] = a[j] * b[j]; c[j].to_bytes(instances_out + 32 * (i * s->n_mul + j)); }
             Rng rng(seed ^ (0xabcdef12345ULL + i));
-            std::vector<uint8_t> p = create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng);
+            std::vector<uint8_t> p = create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng, s->multiopen, s->transcript);
             if (p.size() != proof_len) { bad++; continue; }
             memcpy(proofs + i * proof_len, p.data(), proof_len);
         }
@@ -229,7 +238,7 @@ size_t h2o_prove_shuffle(void* h, uint64_t data_seed, int break_it, uint64_t rng
     for (size_t row = s->H - 1; row >= 1; --row) { size_t r = dr.next() % row; for (auto& col : shuf) std::swap(col[row], col[r]); }
     if (break_it) std::swap(shuf[0][0], shuf[0][1]);
     Rng rng(rng_seed);
-    return copy_out(create_proof(s->pk, s->ck, {}, witness_two_phase_shuffle(orig, shuf), rng), proof, cap);
+    return copy_out(create_proof(s->pk, s->ck, {}, witness_two_phase_shuffle(orig, shuf), rng, s->multiopen, s->transcript), proof, cap);
 }
 // wide circuit: instances_out receives the 8 public inputs; tamper != 0 corrupts one lookup input cell
 size_t h2o_prove_wide(void* h, uint64_t witness_seed, int tamper, uint64_t rng_seed, uint8_t* proof, size_t cap, uint8_t* instances_out) {
@@ -243,7 +252,7 @@ size_t h2o_prove_wide(void* h, uint64_t witness_seed, int tamper, uint64_t rng_s
     WitnessFn w = base;
     if (tamper) w = [base](unsigned ph, const std::vector<Fr>& ch, std::vector<std::vector<Fr>>& adv) { base(ph, ch, adv); if (ph == 0) adv[1][5] = adv[1][5] + Fr::from_u64(123456789); };
     Rng rng(rng_seed);
-    return copy_out(create_proof(s->pk, s->ck, {inst}, w, rng), proof, cap);
+    return copy_out(create_proof(s->pk, s->ck, {inst}, w, rng, s->multiopen, s->transcript), proof, cap);
 }
 
 }  // extern "C"

@@ -228,14 +228,14 @@ std::vector<Fr> interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& v
 }  // namespace
 
 std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, const std::vector<std::vector<Fr>>& instances,
-                                  const WitnessFn& witness, Rng& rng) {
+                                  const WitnessFn& witness, Rng& rng, int multiopen, int transcript) {
     const Circuit& c = pk.circuit; const ConstraintSystem& cs = c.cs;
     const size_t n = c.n(), u = c.usable_rows(), bf = cs.blinding_factors();
     const uint32_t k = c.k, ek = pk.ext_k;
     const size_t m = (size_t)1 << ek, stride = m / n;
     const Ntt& nt = ntt_ctx(k);
     const Fr omega = nt.omega, omega_inv = omega.inv();
-    TranscriptWrite tr;
+    TranscriptWrite tr(transcript);
     tr.common_scalar(pk.vk.transcript_repr);
     for (const auto& col : instances) for (const Fr& v : col) tr.common_scalar(v);
 
@@ -493,6 +493,29 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
     queries.push_back({&h_comb, x, h_eval});
     queries.push_back({&random_poly, x, random_eval});
 
+    if (multiopen == 1) {
+        // GWC opening (gwc.rs:54-135): one witness W_i(X) = sum_j v^j (p_j(X) - e_j) / (X - z_i) per distinct point z_i
+        Fr gv = tr.squeeze_challenge();
+        std::vector<std::pair<Fr, std::vector<const PolyQuery*>>> by_point;
+        for (const PolyQuery& q : queries) {
+            bool found = false;
+            for (auto& e : by_point) if (e.first == q.point) { e.second.push_back(&q); found = true; break; }
+            if (!found) by_point.push_back({q.point, {&q}});
+        }
+        for (auto& e : by_point) {
+            std::vector<Fr> acc(n, Fr::zero());
+            Fr pv = Fr::one();
+            for (const PolyQuery* q : e.second) {
+                for (size_t t = 0; t < n; ++t) acc[t] += pv * (*q->poly)[t];
+                acc[0] -= pv * q->eval;
+                pv *= gv;
+            }
+            divide_by_linear(acc, e.first);
+            tr.write_point(ck.commit_coeff(acc));
+        }
+        tr.squeeze_challenge();  // u: the prover sends nothing after it
+        return tr.out;
+    }
     // SHPLONK opening
     struct PolyPts { const std::vector<Fr>* poly; std::vector<Fr> pts; };
     std::vector<PolyPts> by_poly; std::vector<Fr> super;

@@ -256,17 +256,70 @@ def read_vk_raw(data):
     return vk
 
 
-# ------------------------------------------------------------------ transcript (transcript/mod.rs:104-232)
+# ------------------------------------------------------------------ legacy Keccak-256 (hashlib only has SHA3 padding)
+_KRC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
+        0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
+        0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+        0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_M64 = (1 << 64) - 1
+
+
+def _keccak_f(a):
+    rol = lambda v, n: ((v << n) | (v >> (64 - n))) & _M64 if n else v
+    for rc in _KRC:
+        c = [a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20] for x in range(5)]
+        d = [c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1) for x in range(5)]
+        a = [a[i] ^ d[i % 5] for i in range(25)]
+        # rho + pi, walking the (x, y) -> (y, 2x + 3y) cycle with the triangular-number offsets
+        b = [0] * 25
+        x, y = 1, 0
+        b[0] = a[0]
+        for t in range(24):
+            nx, ny = y, (2 * x + 3 * y) % 5
+            b[nx + 5 * ny] = rol(a[x + 5 * y], ((t + 1) * (t + 2) // 2) % 64)
+            x, y = nx, ny
+        a = [b[i] ^ ((~b[(i % 5 + 1) % 5 + 5 * (i // 5)]) & b[(i % 5 + 2) % 5 + 5 * (i // 5)] & _M64) for i in range(25)]
+        a[0] ^= rc
+    return a
+
+
+def keccak256(data: bytes) -> bytes:
+    rate = 136
+    msg = bytearray(data)
+    pad = rate - len(msg) % rate
+    msg += b"\x01" + b"\x00" * (pad - 1)
+    msg[-1] |= 0x80
+    st = [0] * 25
+    for off in range(0, len(msg), rate):
+        for i in range(17):
+            st[i] ^= int.from_bytes(msg[off + 8 * i:off + 8 * i + 8], "little")
+        st = _keccak_f(st)
+    return b"".join(st[i].to_bytes(8, "little") for i in range(4))
+
+
+# ------------------------------------------------------------------ transcript (transcript/mod.rs:104-272)
+BLAKE2B, KECCAK256 = 0, 1
+SHPLONK, GWC = 0, 1
+
+
 class Transcript:
-    def __init__(self, proof):
+    def __init__(self, proof, kind=BLAKE2B):
+        self.kind = kind
         self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.buf = bytearray(b"Halo2-Transcript")      # Keccak256Read::init absorbs the label (mod.rs:143-145)
         self.r = Reader(proof)
-    def common_scalar(self, s): self.h.update(b"\x02" + s.to_bytes(32, "little"))
+    def _absorb(self, b):
+        if self.kind == KECCAK256: self.buf += b
+        else: self.h.update(b)
+    def common_scalar(self, s): self._absorb(b"\x02" + s.to_bytes(32, "little"))
     def common_point(self, pt):
         if pt is None: raise ValueError("cannot write points at infinity to the transcript")
-        self.h.update(b"\x01" + pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little"))
+        self._absorb(b"\x01" + pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little"))
     def squeeze(self):
-        self.h.update(b"\x00")
+        self._absorb(b"\x00")
+        if self.kind == KECCAK256:   # mod.rs:239-254
+            wide = keccak256(bytes(self.buf) + b"\x0a") + keccak256(bytes(self.buf) + b"\x0b")
+            return int.from_bytes(wide, "little") % R
         return int.from_bytes(self.h.copy().digest(), "little") % R
     def read_point(self):
         pt = g1_decompress(self.r.take(32)); self.common_point(pt); return pt
@@ -298,7 +351,7 @@ def _lagrange_at(points, evals, u):
     return total
 
 
-def guard(params, vk, instances, proof):
+def guard(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
     """Returns dict(challenges, right=[(scalar, point)], left=[(scalar, point)]) or raises (ValueError: transcript
     error with .args[1] in {"transcript", "opening"}; ZeroDivisionError: the reference would panic)."""
     n, k = 1 << vk["k"], vk["k"]
@@ -307,7 +360,7 @@ def guard(params, vk, instances, proof):
     for _ in range(S - k): omega = omega * omega % R
     omega_inv = pow(omega, -1, R)
     rot = lambda x, r_: x * (pow(omega, r_, R) if r_ >= 0 else pow(omega_inv, -r_, R)) % R
-    tr = Transcript(proof)
+    tr = Transcript(proof, transcript)
     try:
         tr.common_scalar(vk["transcript_repr"])
         for col in instances:
@@ -426,6 +479,35 @@ def guard(params, vk, instances, proof):
     for i, c in enumerate(vk["fixed_commitments"]): base[("fix", i)] = c
     for i, c in enumerate(vk["perm_commitments"]): base[("sig", i)] = c
 
+    if multiopen == GWC:   # gwc.rs:54-163
+        try:
+            gv = tr.squeeze()
+            by_point = []
+            for q in Q:
+                for e in by_point:
+                    if e[0] == q[1]: e[1].append(q); break
+                else: by_point.append((q[1], [q]))
+            ws = [tr.read_point() for _ in by_point]
+            gu = tr.squeeze()
+        except ValueError as e:
+            raise ValueError(e.args[0], "opening")
+        commitment_multi, witness, witness_aux, eval_multi = [], [], [], 0
+        for i, ((z, qs), wi) in enumerate(zip(by_point, ws)):
+            pu = pow(gu, i, R)
+            eval_batch = 0
+            for j, (c, _, e) in enumerate(qs):
+                pv = pow(gv, j, R)
+                if c[0] == "hmsm":
+                    for sc, b in h_msm: commitment_multi.append((sc * pv % R * pu % R, b))
+                else:
+                    commitment_multi.append((pv * pu % R, base[c]))
+                eval_batch = (eval_batch + pv * e) % R
+            eval_multi = (eval_multi + pu * eval_batch) % R
+            witness_aux.append((pu * z % R, wi))
+            witness.append((pu, wi))
+        neg_g = (params["g"][0], (-params["g"][1]) % P)
+        return dict(challenges=challenges + [theta, beta, gamma, y, x, gv, gu], right=witness_aux + commitment_multi + [(eval_multi, neg_g)], left=witness)
+
     # shplonk.rs:58-149
     cmap, super_pts = [], set()
     for c, pt, _ in Q:
@@ -479,10 +561,10 @@ def msm(terms):
     return acc
 
 
-def verify_single(params, vk, instances, proof):
+def verify_single(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
     """SingleStrategy: 0 ok, -2 ConstraintSystemFailure, -5 Transcript, -4 Opening, -1 InvalidInstances, -7 panic"""
     try:
-        g = guard(params, vk, instances, proof)
+        g = guard(params, vk, instances, proof, multiopen, transcript)
     except ValueError as e:
         return {"transcript": -5, "opening": -4, "invalid_instances": -1}[e.args[1]]
     except ZeroDivisionError:

@@ -97,32 +97,89 @@ struct Blake2b {
     }
 };
 
+// Legacy Keccak-256 (pad 0x01 .. 0x80, rate 136), as the `sha3 0.9.1` crate's Keccak256 the reference uses for its
+// EVM-style transcript (transcript/mod.rs:110-116,136-151,234-272).  hashlib only has SHA3-256 (different padding),
+// so this is pinned against a pure-Python Keccak in tests/test_oracle_transcript.py.
+struct Keccak256 {
+    u64 st[25];
+    uint8_t buf[136];
+    size_t buflen;
+    Keccak256() { memset(st, 0, sizeof st); buflen = 0; }
+    static inline u64 rotl(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+    static void permute(u64 a[25]) {
+        static const u64 RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+                                   0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                                   0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+                                   0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+        static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+        for (int r = 0; r < 24; ++r) {
+            u64 c[5], d[5], b[25];
+            for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+            for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
+            for (int i = 0; i < 25; ++i) a[i] ^= d[i % 5];
+            for (int x = 0; x < 5; ++x) for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(a[x + 5 * y], ROT[x + 5 * y]);
+            for (int x = 0; x < 5; ++x) for (int y = 0; y < 5; ++y) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+            a[0] ^= RC[r];
+        }
+    }
+    void absorb_block(const uint8_t* b) {
+        for (int i = 0; i < 17; ++i) { u64 w = 0; for (int j = 0; j < 8; ++j) w |= (u64)b[8 * i + j] << (8 * j); st[i] ^= w; }
+        permute(st);
+    }
+    void update(const uint8_t* in, size_t n) {
+        while (n > 0) {
+            size_t take = 136 - buflen; if (take > n) take = n;
+            memcpy(buf + buflen, in, take); buflen += take; in += take; n -= take;
+            if (buflen == 136) { absorb_block(buf); buflen = 0; }
+        }
+    }
+    void finalize(uint8_t out[32]) const {
+        Keccak256 c = *this;
+        memset(c.buf + c.buflen, 0, 136 - c.buflen);
+        c.buf[c.buflen] ^= 0x01; c.buf[135] ^= 0x80;
+        c.absorb_block(c.buf);
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)(c.st[i] >> (8 * j));
+    }
+};
+
+enum TranscriptKind { TR_BLAKE2B = 0, TR_KECCAK256 = 1 };
+
 // Error strings mirror the reference's io::Error = &'static str values.
 struct TranscriptError { const char* what; };
 
 struct TranscriptBase {
+    int kind;
     Blake2b state;
-    TranscriptBase() : state("Halo2-Transcript") {}
+    Keccak256 kstate;
+    explicit TranscriptBase(int k = TR_BLAKE2B) : kind(k), state("Halo2-Transcript") {
+        if (kind == TR_KECCAK256) kstate.update((const uint8_t*)"Halo2-Transcript", 16);   // transcript/mod.rs:143-145
+    }
+    void absorb(const uint8_t* b, size_t n) { if (kind == TR_KECCAK256) kstate.update(b, n); else state.update(b, n); }
     Fr squeeze_challenge() {
-        uint8_t z = 0; state.update(&z, 1);
-        uint8_t out[64]; state.finalize(out);
+        uint8_t z = 0; absorb(&z, 1);
+        uint8_t out[64];
+        if (kind == TR_KECCAK256) {   // transcript/mod.rs:239-254: two clones with suffix 10 / 11, 32 bytes each
+            Keccak256 lo = kstate, hi = kstate;
+            uint8_t a = 10, b = 11; lo.update(&a, 1); hi.update(&b, 1);
+            lo.finalize(out); hi.finalize(out + 32);
+        } else state.finalize(out);
         return Fr::from_uniform_bytes(out);
     }
     void common_point(const G1Affine& p) {
         if (p.inf) throw TranscriptError{"cannot write points at infinity to the transcript"};
         uint8_t b[65]; b[0] = 1; p.x.to_bytes(b + 1); p.y.to_bytes(b + 33);
-        state.update(b, 65);
+        absorb(b, 65);
     }
     void common_scalar(const Fr& s) {
         uint8_t b[33]; b[0] = 2; s.to_bytes(b + 1);
-        state.update(b, 33);
+        absorb(b, 33);
     }
 };
 
 // == Blake2bRead<&[u8], G1Affine, Challenge255<_>>
 struct TranscriptRead : TranscriptBase {
     const uint8_t* data; size_t len, pos;
-    TranscriptRead(const uint8_t* d, size_t n) : data(d), len(n), pos(0) {}
+    TranscriptRead(const uint8_t* d, size_t n, int kind = TR_BLAKE2B) : TranscriptBase(kind), data(d), len(n), pos(0) {}
     G1Affine read_point() {
         if (pos + 32 > len) throw TranscriptError{"failed to fill whole buffer"};
         G1Affine p;
@@ -144,6 +201,7 @@ struct TranscriptRead : TranscriptBase {
 // == Blake2bWrite (transcript/mod.rs:336-398); used only by the test-only prover
 struct TranscriptWrite : TranscriptBase {
     std::vector<uint8_t> out;
+    explicit TranscriptWrite(int kind = TR_BLAKE2B) : TranscriptBase(kind) {}
     void write_point(const G1Affine& p) {
         common_point(p);
         uint8_t b[32]; g1_to_bytes(p, b);

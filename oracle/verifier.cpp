@@ -203,11 +203,11 @@ static void construct_intermediate_sets(const std::vector<VQuery>& queries, std:
 
 // ------------------------------------------------------------------ lib.rs:33-425
 Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
-                   const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace, const char** err_msg) {
+                   const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace, const char** err_msg, VerifyOptions opts) {
     const ConstraintSystem& cs = vk.cs;
     if (instances.size() != cs.num_instance_columns) return InvalidInstances;  // lib.rs:51-55
     Domain domain(vk.cs_degree, vk.k);
-    TranscriptRead tr(proof, proof_len);
+    TranscriptRead tr(proof, proof_len, opts.transcript);
     bool in_opening = false;
     try {
         tr.common_scalar(vk.transcript_repr);                                   // vk.rs:145-152
@@ -411,8 +411,50 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
             }
         };
 
-        // ---------------------------------------------------------------- shplonk.rs:175-267
         in_opening = true;
+        if (opts.multiopen == MO_GWC) {
+            // ------------------------------------------------------------ gwc.rs:54-163
+            Fr gv = tr.squeeze_challenge();
+            std::vector<std::pair<Fr, std::vector<const VQuery*>>> by_point;   // first-appearance order of points (gwc.rs:138-163)
+            for (const VQuery& q : queries) {
+                bool found = false;
+                for (auto& e : by_point) if (e.first == q.point) { e.second.push_back(&q); found = true; break; }
+                if (!found) by_point.push_back({q.point, {&q}});
+            }
+            std::vector<G1Affine> w(by_point.size());
+            for (auto& wi : w) wi = tr.read_point();
+            Fr gu = tr.squeeze_challenge();
+            MSMKZG commitment_multi, witness, witness_with_aux;
+            Fr eval_multi = Fr::zero(), power_of_u = Fr::one();
+            for (size_t i = 0; i < by_point.size(); ++i, power_of_u = gu * power_of_u) {
+                MSMKZG commitment_batch; Fr eval_batch = Fr::zero(), power_of_v = Fr::one();
+                for (const VQuery* q : by_point[i].second) {
+                    MSMKZG msm;
+                    if (q->c.kind == K_H_MSM) { msm = h_commitment; msm.scale(power_of_v); }
+                    else msm.append_term(power_of_v, G1::from_affine(base_of(q->c)));
+                    commitment_batch.add_msm(msm);
+                    eval_batch += power_of_v * q->eval;
+                    power_of_v = gv * power_of_v;
+                }
+                commitment_batch.scale(power_of_u);
+                commitment_multi.add_msm(commitment_batch);
+                eval_multi += power_of_u * eval_batch;
+                witness_with_aux.append_term(power_of_u * by_point[i].first, G1::from_affine(w[i]));
+                witness.append_term(power_of_u, G1::from_affine(w[i]));
+            }
+            acc.left.add_msm(witness);
+            acc.right.add_msm(witness_with_aux);
+            acc.right.add_msm(commitment_multi);
+            acc.right.append_term(eval_multi, G1::from_affine(params.g).neg());
+            if (trace) {
+                trace->challenges = challenges;
+                trace->theta = theta; trace->beta = beta; trace->gamma = gamma; trace->y = y; trace->x = x;
+                trace->sh_y = Fr::zero(); trace->sh_v = gv; trace->sh_u = gu;
+                trace->expected_h_eval = expected_h_eval; trace->expressions = exprs;
+            }
+            return OK;
+        }
+        // ---------------------------------------------------------------- shplonk.rs:175-267
         std::vector<RotationSet> rotation_sets; PointSet super;
         construct_intermediate_sets(queries, rotation_sets, super);
         Fr sy = tr.squeeze_challenge();
@@ -477,17 +519,17 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
 }
 
 Error verify_single(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
-                    const uint8_t* proof, size_t proof_len) {
+                    const uint8_t* proof, size_t proof_len, VerifyOptions opts) {
     DualMSM msm;
-    Error e = verify_proof(params, vk, instances, proof, proof_len, msm);
+    Error e = verify_proof(params, vk, instances, proof, proof_len, msm, nullptr, nullptr, opts);
     if (e != OK) return e;
     return msm.check(params) ? OK : ConstraintSystemFailure;
 }
 
 Error AccumulatorStrategy::process(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
-                                   const uint8_t* proof, size_t proof_len, const Fr& rand) {
+                                   const uint8_t* proof, size_t proof_len, const Fr& rand, VerifyOptions opts) {
     acc.scale(rand);  // strategy.rs:129 — before the closure runs
-    return verify_proof(params, vk, instances, proof, proof_len, acc);
+    return verify_proof(params, vk, instances, proof, proof_len, acc, nullptr, nullptr, opts);
 }
 
 // ------------------------------------------------------------------ G2 compressed encoding

@@ -10,6 +10,7 @@
 //   permutation / lookup / shuffle / vanishing   plonk/{permutation,lookup,shuffle,vanishing}.rs
 //   verify_proof                      lib.rs:33-425
 //   VerifierSHPLONK::verify_proof     poly/kzg/multiopen/shplonk.rs:58-267
+//   VerifierGWC::verify_proof         poly/kzg/multiopen/gwc.rs:54-163
 //   SingleStrategy / AccumulatorStrategy   poly/kzg/strategy.rs:55-181
 // PARITY PINNING: the reference holds no proof/VK/MSM golden values; what it
 // does hold — params/kzg_bn254_8.srs — pins field/curve encodings, omega, 256 MSM answers and
@@ -82,20 +83,25 @@ struct VerifyTrace {
 // lib.rs:33-425 with V = VerifierSHPLONK, transcript = Blake2bRead, one circuit instance per
 // transcript (instances.len() == 1, as in every reference caller).  Appends this proof's terms
 // to `acc` exactly as the closure passed to strategy.process does (shplonk.rs:256-264).
+// The generic parameters of verify_proof the reference instantiates (lib.rs:33-40): V in {VerifierSHPLONK, VerifierGWC}
+// (poly/kzg/multiopen/{shplonk,gwc}.rs), T in {Blake2bRead, Keccak256Read} (transcript/mod.rs:104-116).
+enum MultiOpen { MO_SHPLONK = 0, MO_GWC = 1 };
+struct VerifyOptions { int multiopen = MO_SHPLONK; int transcript = TR_BLAKE2B; };
+
 Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
                    const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace = nullptr,
-                   const char** err_msg = nullptr);
+                   const char** err_msg = nullptr, VerifyOptions opts = VerifyOptions());
 
 // poly/kzg/strategy.rs:164-176
 Error verify_single(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
-                    const uint8_t* proof, size_t proof_len);
+                    const uint8_t* proof, size_t proof_len, VerifyOptions opts = VerifyOptions());
 
 // poly/kzg/strategy.rs:125-140.  `rand` holds the Fr::random draw of each process() call
 // (strategy.rs:129), injectable so results are reproducible.
 struct AccumulatorStrategy {
     DualMSM acc;
     Error process(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
-                  const uint8_t* proof, size_t proof_len, const Fr& rand);
+                  const uint8_t* proof, size_t proof_len, const Fr& rand, VerifyOptions opts = VerifyOptions());
     bool finalize(const ParamsKZG& params) const { return acc.check(params); }
 };
 

@@ -16,14 +16,29 @@ def le32(x):
     return int(x).to_bytes(32, "little")
 
 
+SHPLONK, GWC = 0, 1          # multi-open argument (poly/kzg/multiopen/{shplonk,gwc}.rs)
+BLAKE2B, KECCAK256 = 0, 1    # transcript hash (transcript/mod.rs:104-116)
+
+
 class Setup:
     def __init__(self, L, handle, ninst_cols):
         self.L, self.h, self.ninst_cols = L, handle, ninst_cols
+        self.multiopen, self.transcript = SHPLONK, BLAKE2B
         buf = ctypes.create_string_buffer(1 << 22)
         n = L.h2o_setup_vk(handle, RAW, buf, len(buf))
         self.vk = buf.raw[:n]
         n = L.h2o_setup_params(handle, RAW, buf, len(buf))
         self.params = buf.raw[:n]
+
+    def set_options(self, multiopen=SHPLONK, transcript=BLAKE2B):
+        """Options of both the test prover and the oracle verifier for this setup."""
+        self.multiopen, self.transcript = multiopen, transcript
+        self.L.h2o_setup_set_options(self.h, multiopen, transcript)
+        return self
+
+    def use(self):
+        """Select this setup's options for the oracle's verifier entry points (thread-local on the C side)."""
+        self.L.h2o_set_verify_options(self.multiopen, self.transcript)
 
     def free(self):
         if self.h:
@@ -52,7 +67,9 @@ def prove_vector_mul(s, a, b, rng_seed=7):
     return buf.raw[:n], [[inst.raw[32 * i:32 * i + 32] for i in range(s.n_mul)]]
 
 
-def prove_vector_mul_batch(s, count, seed=1, threads=8, proof_len=1024):
+def prove_vector_mul_batch(s, count, seed=1, threads=8, proof_len=None):
+    if proof_len is None:
+        proof_len = len(prove_vector_mul(s, [1] * s.n_mul, [1] * s.n_mul)[0])
     proofs = ctypes.create_string_buffer(count * proof_len)
     inst = ctypes.create_string_buffer(count * 32 * s.n_mul)
     got = s.L.h2o_prove_vector_mul_batch(s.h, count, seed, threads, proofs, proof_len, inst)
@@ -98,12 +115,21 @@ def _flat(instances):
     return flat, (ctypes.c_size_t * max(len(lens), 1))(*lens), len(lens)
 
 
+def _use(s):
+    if hasattr(s, "use"):
+        s.use()
+    else:
+        s.L.h2o_set_verify_options(getattr(s, "multiopen", 0), getattr(s, "transcript", 0))
+
+
 def oracle_verify_single(s, proof, instances):
+    _use(s)
     f, cl, nc = _flat(instances)
     return s.L.h2o_verify_single(s.params, len(s.params), RAW, s.vk, len(s.vk), RAW, f, cl, nc, proof, len(proof))
 
 
 def oracle_guard(s, proof, instances, cap=4096):
+    _use(s)
     f, cl, nc = _flat(instances)
     rs, rb = ctypes.create_string_buffer(32 * cap), ctypes.create_string_buffer(64 * cap)
     ls, lb = ctypes.create_string_buffer(32 * 16), ctypes.create_string_buffer(64 * 16)
@@ -118,6 +144,7 @@ def oracle_guard(s, proof, instances, cap=4096):
 
 
 def oracle_verify_batch(s, proofs, instances, rand):
+    _use(s)
     n = len(proofs)
     plen = len(proofs[0]) if n else 0
     assert all(len(p) == plen for p in proofs)

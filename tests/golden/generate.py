@@ -26,26 +26,41 @@ import pyref  # noqa: E402
 R = pyref.R
 
 
+def aggregate(terms):
+    """[(scalar, point)] -> the same list with repeated bases merged (first-appearance order, scalars summed mod r).
+    This is how the C ABI reports a GWC Guard (include/h2v.h, h2v_guard_msm)."""
+    order, acc = [], {}
+    for sc, b in terms:
+        key = pyref.g1_xy(b)
+        if key not in acc:
+            order.append(key); acc[key] = 0
+        acc[key] = (acc[key] + sc) % R
+    return [(acc[k], k) for k in order]
+
+
 def case(name, s, proofs, rand_seed, notes):
     params, vk = pyref.read_params_raw(s.params), pyref.read_vk_raw(s.vk)
+    mo, trk = s.multiopen, s.transcript
     out = dict(name=name, notes=notes, g1_flag_layout="byte31: bit7 identity, bit6 sign(y)", serde_format="RawBytes",
-               params=s.params.hex(), vk=s.vk.hex(), proofs=[])
+               multiopen=mo, transcript=trk, params=s.params.hex(), vk=s.vk.hex(), proofs=[])
     guards = []
     for label, proof, inst in proofs:
         insts = [[int.from_bytes(v, "little") for v in col] for col in inst]
         entry = dict(label=label, proof=proof.hex(), instances=[[v.hex() for v in col] for col in inst])
         try:
-            g = pyref.guard(params, vk, insts, proof)
+            g = pyref.guard(params, vk, insts, proof, mo, trk)
             entry["guard_status"] = 0
             entry["challenges"] = [c.to_bytes(32, "little").hex() for c in g["challenges"]]
-            entry["right_scalars"] = [sc.to_bytes(32, "little").hex() for sc, _ in g["right"]]
-            entry["right_bases"] = [pyref.g1_xy(b).hex() for _, b in g["right"]]
-            entry["left_base"] = pyref.g1_xy(g["left"][0][1]).hex()
+            agg = aggregate(g["right"])
+            entry["right_scalars"] = [sc.to_bytes(32, "little").hex() for sc, _ in agg]
+            entry["right_bases"] = [b.hex() for _, b in agg]
+            entry["left_scalars"] = [sc.to_bytes(32, "little").hex() for sc, _ in g["left"]]
+            entry["left_bases"] = [pyref.g1_xy(b).hex() for _, b in g["left"]]
             guards.append(g)
         except ValueError as e:
             entry["guard_status"] = {"transcript": -5, "opening": -4}[e.args[1]]
             guards.append(None)
-        entry["single_status"] = pyref.verify_single(params, vk, insts, proof)
+        entry["single_status"] = pyref.verify_single(params, vk, insts, proof, mo, trk)
         out["proofs"].append(entry)
     # AccumulatorStrategy over all proofs with seeded draws: acc = sum_i (prod_{j>i} r_j) msm_i  (kzg/strategy.rs:125-136)
     rnd = random.Random(rand_seed)
@@ -95,6 +110,18 @@ def main():
     case("wide_lookup_shuffle", s, [("valid", good, inst), ("lookup_input_not_in_table", bad, inst_b)], 5,
          "12 advice, 6 fixed, 2 lookups (2-column), 1 shuffle argument, degree 5; second proof violates a lookup")
     s.free()
+    # 5. the other instantiations of verify_proof's generic parameters: GWC multi-open, Keccak-256 transcript
+    for mo, trk, tag in ((circuits.GWC, circuits.BLAKE2B, "gwc_blake2b"), (circuits.SHPLONK, circuits.KECCAK256, "shplonk_keccak"), (circuits.GWC, circuits.KECCAK256, "gwc_keccak")):
+        s = circuits.setup_wide(8, A=8, F=5, L_=1, Sh=1, deg=4).set_options(mo, trk)
+        good, inst = circuits.prove_wide(s, witness_seed=9)
+        bad, inst_b = circuits.prove_wide(s, witness_seed=9, tamper=True)
+        case("wide_" + tag, s, [("valid", good, inst), ("lookup_input_not_in_table", bad, inst_b)], 6, "8 advice, 5 fixed, 1 lookup, 1 shuffle, degree 4; " + tag)
+        s.free()
+        s = circuits.setup_shuffle(8, 4, 32).set_options(mo, trk)
+        good, inst = circuits.prove_shuffle(s, data_seed=5)
+        bad, _ = circuits.prove_shuffle(s, data_seed=5, break_it=True)
+        case("two_phase_shuffle_" + tag, s, [("valid", good, inst), ("broken_shuffle", bad, inst)], 7, "W=4, H=32; " + tag)
+        s.free()
 
 
 if __name__ == "__main__":

@@ -41,6 +41,11 @@ def load():
     L.h2o_setup_shuffle.argtypes = [c.c_uint32, c.c_size_t, c.c_size_t, c.c_char_p, c.c_size_t, c.c_uint64]
     L.h2o_setup_wide.argtypes = [c.c_uint32, c.c_size_t, c.c_size_t, c.c_size_t, c.c_size_t, c.c_uint32, c.c_uint64, c.c_char_p, c.c_size_t, c.c_uint64]
     L.h2o_setup_free.argtypes = [c.c_void_p]
+    L.h2o_setup_set_options.argtypes = [c.c_void_p, c.c_int, c.c_int]
+    L.h2o_setup_set_options.restype = None
+    L.h2o_set_verify_options.argtypes = [c.c_int, c.c_int]
+    L.h2o_set_verify_options.restype = None
+    L.h2o_keccak256.argtypes = [c.c_char_p, c.c_size_t, c.c_char_p]
     L.h2o_setup_vk.restype = c.c_size_t
     L.h2o_setup_vk.argtypes = [c.c_void_p, c.c_int, c.c_char_p, c.c_size_t]
     L.h2o_setup_params.restype = c.c_size_t

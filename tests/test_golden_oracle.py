@@ -13,6 +13,7 @@ class _S:  # the subset of circuits.Setup the oracle helpers use
     def __init__(self, L, case):
         self.L, self.params, self.vk = L, h(case["params"]), h(case["vk"])
         self.ninst_cols = len(case["proofs"][0]["instances"])
+        self.multiopen, self.transcript = case.get("multiopen", 0), case.get("transcript", 0)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
@@ -26,9 +27,10 @@ def test_oracle_matches_golden(oracle, case):
         assert rc == e["guard_status"], e["label"]
         if rc == 0:
             assert [c.hex() for c in g["challenges"]] == e["challenges"]
-            assert [c.hex() for c in g["right_scalars"]] == e["right_scalars"]
-            assert [c.hex() for c in g["right_bases"]] == e["right_bases"]
-            assert g["left_bases"][0].hex() == e["left_base"] and int.from_bytes(g["left_scalars"][0], "little") == 1
+            agg_s, agg_b = golden_util.aggregate(g["right_scalars"], g["right_bases"])
+            assert [c.hex() for c in agg_s] == e["right_scalars"]
+            assert [c.hex() for c in agg_b] == e["right_bases"]
+            assert [c.hex() for c in g["left_scalars"]] == e["left_scalars"] and [c.hex() for c in g["left_bases"]] == e["left_bases"]
         assert circuits.oracle_verify_single(s, proof, inst) == e["single_status"], e["label"]
     b = case["batch"]
     ok, st, left, right = circuits.oracle_verify_batch(s, proofs, insts, [h(r) for r in b["rand"]])

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 def _ctx(s):
     import halo2_verifier_amd as h2v
-    return h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
+    return h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes),
+                       multiopen=s.multiopen, transcript=s.transcript)
 
 
 @pytest.fixture(scope="module")
@@ -40,8 +41,10 @@ def _check_guard(ctx, s, proof, inst):
     assert rc_o == rc_g
     if rc_o == 0:
         assert g_g["challenges"] == g_o["challenges"]
-        assert g_g["right_bases"] == g_o["right_bases"]
-        assert g_g["right_scalars"] == g_o["right_scalars"]
+        import golden_util
+        agg_s, agg_b = golden_util.aggregate(g_o["right_scalars"], g_o["right_bases"])   # no-op for SHPLONK (distinct bases)
+        assert g_g["right_bases"] == agg_b
+        assert g_g["right_scalars"] == agg_s
         assert g_g["left_scalars"] == g_o["left_scalars"] and g_g["left_bases"] == g_o["left_bases"]
     return rc_o
 
@@ -154,4 +157,46 @@ def test_wide_circuit_lookups_shuffles(shape):
     got = ctx.verify_batch([good] * 3, [inst] * 3, rand)
     assert got == circuits.oracle_verify_batch(s, [good] * 3, [inst] * 3, rand)
     assert got[0] is True
+    ctx.close(); s.free()
+
+
+@pytest.mark.parametrize("mo,trk", [(circuits.GWC, circuits.BLAKE2B), (circuits.SHPLONK, circuits.KECCAK256), (circuits.GWC, circuits.KECCAK256)])
+def test_gwc_and_keccak_variants(mo, trk):
+    """The other instantiations of verify_proof's generic parameters (lib.rs:33-40): VerifierGWC, Keccak256Read."""
+    rnd = random.Random(mo * 2 + trk)
+    # vector_mul batch incl. malformed proofs
+    s = circuits.setup_vector_mul(8, 10).set_options(mo, trk)
+    ctx = _ctx(s)
+    P, I = circuits.prove_vector_mul_batch(s, 9, seed=6, threads=8)
+    plen = len(P[0])
+    assert ctx.proof_shape()["proof_len"] == plen
+    for i in range(3):
+        assert _check_guard(ctx, s, P[i], I[i]) == 0
+    rand = [rnd.randrange(1, R_MOD) for _ in range(9)]
+    assert ctx.verify_batch(P, I, rand) == circuits.oracle_verify_batch(s, P, I, rand)
+    P2 = list(P)
+    b = bytearray(P2[2]); b[plen - 1] ^= 0x40; P2[2] = bytes(b)        # last opening point: sign flipped
+    b = bytearray(P2[4]); b[13 * 32 + 31] = 0xff; P2[4] = bytes(b)      # non-canonical evaluation
+    b = bytearray(P2[6]); b[plen - 32:plen] = b"\x00" * 31 + b"\x80"; P2[6] = bytes(b)   # identity encoding in the multi-open part
+    exp = circuits.oracle_verify_batch(s, P2, I, rand)
+    assert ctx.verify_batch(P2, I, rand) == exp and exp[1][4] == -5 and exp[1][6] == -4 and exp[0] is False
+    assert ctx.verify_each(P2, I) == [circuits.oracle_verify_single(s, p, i) for p, i in zip(P2, I)]
+    ctx.close(); s.free()
+    # two-phase circuit with user challenges
+    s = circuits.setup_shuffle(8, 4, 32).set_options(mo, trk)
+    ctx = _ctx(s)
+    good, inst = circuits.prove_shuffle(s, data_seed=8)
+    bad, _ = circuits.prove_shuffle(s, data_seed=8, break_it=True)
+    assert _check_guard(ctx, s, good, inst) == 0
+    assert ctx.verify_each([good, bad], [inst, inst]) == [0, -2] == [circuits.oracle_verify_single(s, p, inst) for p in (good, bad)]
+    ctx.close(); s.free()
+    # lookups + shuffle argument
+    s = circuits.setup_wide(8, A=12, F=6, L_=2, Sh=1, deg=5).set_options(mo, trk)
+    ctx = _ctx(s)
+    good, inst = circuits.prove_wide(s, witness_seed=4)
+    bad, inst_b = circuits.prove_wide(s, witness_seed=4, tamper=True)
+    assert _check_guard(ctx, s, good, inst) == 0
+    assert ctx.verify_each([good, bad], [inst, inst_b]) == [0, -2]
+    rand = [3, 5]
+    assert ctx.verify_batch([good, good], [inst, inst], rand) == circuits.oracle_verify_batch(s, [good, good], [inst, inst], rand)
     ctx.close(); s.free()

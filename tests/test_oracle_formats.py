@@ -24,6 +24,7 @@ def test_params_and_vk_round_trip_between_serde_formats(oracle):
     proof, inst = circuits.prove_wide(s, witness_seed=3)
     f = b"".join(b"".join(c) for c in inst)
     cl = (ctypes.c_size_t * 1)(8)
+    oracle.h2o_set_verify_options(0, 0)   # SHPLONK + Blake2b (the options are thread-local state on the C side)
     assert oracle.h2o_verify_single(p_proc, len(p_proc), 0, v_proc, len(v_proc), 0, f, cl, 1, proof, len(proof)) == 0
     s.free()
 
