@@ -200,3 +200,24 @@ def test_gwc_and_keccak_variants(mo, trk):
     rand = [3, 5]
     assert ctx.verify_batch([good, good], [inst, inst], rand) == circuits.oracle_verify_batch(s, [good, good], [inst, inst], rand)
     ctx.close(); s.free()
+
+
+def test_lookup_heavy_vk_shape():
+    """BASELINE.json config 4 shape: 32 advice, 16 fixed, 8 two-column lookups, rotations -1/0/+1 on a quarter of
+    the advice columns, degree-5 gates, 33 permutation columns in 11 sets.  k is kept small here (verifier work does not depend on k)."""
+    s = circuits.setup_wide(9, A=32, F=16, L_=8, Sh=0, deg=5)
+    ctx = _ctx(s)
+    shape = ctx.proof_shape()
+    assert shape["n_points"] == 32 + 3 * 8 + 11 + 1 + 4 + 2 and shape["n_scalars"] == 48 + 16 + 1 + 33 + 32 + 40
+    P, I = [], []
+    for seed in range(6):
+        p, i = circuits.prove_wide(s, witness_seed=seed, rng_seed=100 + seed)
+        P.append(p); I.append(i)
+    assert _check_guard(ctx, s, P[0], I[0]) == 0
+    rnd = random.Random(16)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(6)]
+    got = ctx.verify_batch(P, I, rand)
+    assert got == circuits.oracle_verify_batch(s, P, I, rand) and got[0] is True
+    bad, inst_b = circuits.prove_wide(s, witness_seed=0, tamper=True)
+    assert ctx.verify_each([P[0], bad], [I[0], inst_b]) == [0, -2]
+    ctx.close(); s.free()

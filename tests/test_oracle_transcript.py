@@ -84,3 +84,23 @@ def test_challenges_of_a_real_proof_follow_the_python_restatement(oracle):
     got = [int.from_bytes(c, "little") for c in g["challenges"]]
     assert got == [theta, beta, gamma, y, x, sy, sv, su]
     s.free()
+
+
+def test_keccak256_matches_python_restatement_and_known_vectors(oracle):
+    """Legacy Keccak-256 (sha3 0.9.1's Keccak256, not SHA3-256): known answers + the independent Python implementation in oracle/pyref.py."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref
+
+    def k(data):
+        out = ctypes.create_string_buffer(32)
+        oracle.h2o_keccak256(data, len(data), out)
+        return out.raw
+
+    assert k(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert k(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    assert k(b"").hex() != hashlib.sha3_256(b"").hexdigest()
+    rnd = random.Random(9)
+    for n in (1, 55, 134, 135, 136, 137, 271, 272, 273, 1000):
+        data = bytes(rnd.randrange(256) for _ in range(n))
+        assert k(data) == pyref.keccak256(data), n
