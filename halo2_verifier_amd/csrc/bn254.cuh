@@ -40,6 +40,10 @@ struct FqParams {
         constexpr uint32_t v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
         return v[i];
     }
+    H2V_HD static constexpr uint32_t R3(int i) {  // R^3 mod p
+        constexpr uint32_t v[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u, 0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};
+        return v[i];
+    }
 };
 struct FrParams {
     static constexpr uint32_t INV = 0xefffffffu;
@@ -53,6 +57,10 @@ struct FrParams {
     }
     H2V_HD static constexpr uint32_t R2(int i) {
         constexpr uint32_t v[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return v[i];
+    }
+    H2V_HD static constexpr uint32_t R3(int i) {
+        constexpr uint32_t v[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
         return v[i];
     }
 };
@@ -209,12 +217,48 @@ template <class PR> struct Fp {
         }
         return r;
     }
-    // Fermat inverse x^(p-2); inv(0) = 0
-    H2V_FN Fp inv() const {
+    // Fermat inverse x^(p-2); inv(0) = 0.  Kept as the cross-check of inv().
+    H2V_FN Fp inv_fermat() const {
         uint32_t e[8];
         for (int i = 0; i < 8; ++i) e[i] = PR::P(i);
         e[0] -= 2;  // p is odd and its low limb is >= 2 for both fields
         return pow_limbs(e);
+    }
+    // Inverse by the binary extended Euclidean algorithm on the raw limbs: <= 2*254 shift/subtract steps of ~70
+    // instructions instead of 320 Montgomery products of ~600 — about 5x fewer instructions on the lanes' critical
+    // path (the Fr program's one inversion per proof, the affine conversions, the Fq12 inversion of the pairing).
+    // Works on the Montgomery limbs m = aR as a plain integer: m^-1 = a^-1 R^-1, and one product with R^3 gives a^-1 R.
+    // inv(0) = 0.  The loop is bounded, so every lane leaves it.
+    H2V_FN Fp inv() const {
+        if (is_zero()) return zero();
+        uint32_t u[8], w[8], x1[8], x2[8];
+        for (int i = 0; i < 8; ++i) { u[i] = v[i]; w[i] = PR::P(i); x1[i] = i == 0 ? 1u : 0u; x2[i] = 0u; }
+        auto is_one = [](const uint32_t a[8]) { uint32_t o = a[0] ^ 1u; for (int i = 1; i < 8; ++i) o |= a[i]; return o == 0; };
+        auto shr1 = [](uint32_t a[8], uint32_t top) { for (int i = 0; i < 7; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31); a[7] = (a[7] >> 1) | (top << 31); };
+        auto halve_mod = [&](uint32_t x[8]) {  // x <- x / 2 mod p
+            uint32_t carry = 0;
+            if (x[0] & 1u) { for (int i = 0; i < 8; ++i) { uint64_t t = (uint64_t)x[i] + PR::P(i) + carry; x[i] = (uint32_t)t; carry = (uint32_t)(t >> 32); } }
+            shr1(x, carry);
+        };
+        auto sub_raw = [](uint32_t a[8], const uint32_t b[8]) {  // a <- a - b, returns borrow
+            uint32_t borrow = 0;
+            for (int i = 0; i < 8; ++i) { uint64_t t = (uint64_t)a[i] - b[i] - borrow; a[i] = (uint32_t)t; borrow = (uint32_t)(t >> 32) & 1u; }
+            return borrow;
+        };
+        auto sub_mod = [&](uint32_t a[8], const uint32_t b[8]) {  // a <- a - b mod p
+            if (sub_raw(a, b)) { uint32_t carry = 0; for (int i = 0; i < 8; ++i) { uint64_t t = (uint64_t)a[i] + PR::P(i) + carry; a[i] = (uint32_t)t; carry = (uint32_t)(t >> 32); } }
+        };
+        auto geq = [](const uint32_t a[8], const uint32_t b[8]) { for (int i = 7; i >= 0; --i) { if (a[i] > b[i]) return true; if (a[i] < b[i]) return false; } return true; };
+        for (int iter = 0; iter < 1024 && !is_one(u) && !is_one(w); ++iter) {
+            if (!(u[0] & 1u)) { shr1(u, 0); halve_mod(x1); }
+            else if (!(w[0] & 1u)) { shr1(w, 0); halve_mod(x2); }
+            else if (geq(u, w)) { sub_raw(u, w); sub_mod(x1, x2); shr1(u, 0); halve_mod(x1); }   // both odd: the difference is even
+            else { sub_raw(w, u); sub_mod(x2, x1); shr1(w, 0); halve_mod(x2); }
+        }
+        Fp t, r3;
+        const bool from_u = is_one(u);
+        for (int i = 0; i < 8; ++i) { t.v[i] = from_u ? x1[i] : x2[i]; r3.v[i] = PR::R3(i); }
+        return mul(t, r3);
     }
     H2V_HD bool is_odd() const { uint32_t raw[8]; to_raw(raw); return raw[0] & 1; }
     // numeric order of canonical values: -1, 0, 1

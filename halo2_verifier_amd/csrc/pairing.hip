@@ -24,7 +24,9 @@ namespace h2v {
 #define N_LINES 102  // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
 
 struct WaveShared {
-    Fq2 line[2][N_LINES][3];  // per pair: coefficient of w^0, w^1, w^3 of every line, already evaluated at P
+    // step i of the Miller loop multiplies f by l0_i(P0) * l1_i(P1).  The two sparse lines (coefficients of w^0, w^1, w^3,
+    // evaluated at their point) are written here first, then replaced in place by their 6-coefficient product.
+    Fq2 line[N_LINES][6];
     Fq2 prod[36];
     Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6], L[6];
 };
@@ -99,29 +101,35 @@ __global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pai
     for (uint32_t t = lane; t < 2 * N_LINES; t += 64) {
         const uint32_t pr = t / N_LINES, li = t % N_LINES;
         const LineCoeff c = pr ? l_ng2[li] : l_sg2[li];
-        s.line[pr][li][0] = c.a.scale(pr ? P1.Y : P0.Y);
-        s.line[pr][li][1] = c.b.scale(pr ? xz1 : xz0);
-        s.line[pr][li][2] = c.c.scale(pr ? z31 : z30);
+        s.line[li][3 * pr + 0] = c.a.scale(pr ? P1.Y : P0.Y);
+        s.line[li][3 * pr + 1] = c.b.scale(pr ? xz1 : xz0);
+        s.line[li][3 * pr + 2] = c.c.scale(pr ? z31 : z30);
     }
     if (lane < 6) s.f[lane] = lane == 0 ? Fq2::one() : Fq2::zero();
     __syncthreads();
-    // Miller loop
+    // all per-step line products up front, one lane per step, in place:
+    //   (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
+    // an identity point contributes the line value 1
+    for (uint32_t li = lane; li < N_LINES; li += 64) {
+        Fq2 a0 = s.line[li][0], b0 = s.line[li][1], c0 = s.line[li][2], a1 = s.line[li][3], b1 = s.line[li][4], c1 = s.line[li][5];
+        if (skip0) { a0 = Fq2::one(); b0 = Fq2::zero(); c0 = Fq2::zero(); }
+        if (skip1) { a1 = Fq2::one(); b1 = Fq2::zero(); c1 = Fq2::zero(); }
+        Fq2 a0a1 = a0 * a1, b0b1 = b0 * b1, c0c1 = c0 * c1;
+        Fq2 ab = (a0 + b0) * (a1 + b1) - a0a1 - b0b1;          // a0b1 + b0a1
+        Fq2 ac = (a0 + c0) * (a1 + c1) - a0a1 - c0c1;          // a0c1 + c0a1
+        Fq2 bc = (b0 + c0) * (b1 + c1) - b0b1 - c0c1;          // b0c1 + c0b1
+        s.line[li][0] = a0a1 + c0c1.mul_xi(); s.line[li][1] = ab; s.line[li][2] = b0b1; s.line[li][3] = ac; s.line[li][4] = bc; s.line[li][5] = Fq2::zero();
+    }
+    __syncthreads();
+    // Miller loop: one squaring and one product per doubling step, one more product per addition step
     uint32_t idx = 0;
     for (int i = 63; i >= 0; --i) {
         wmul(s, s.f, s.f, s.f, lane);
-        if (!skip0) wmul_line(s, s.f, s.f, s.line[0][idx], lane);
-        if (!skip1) wmul_line(s, s.f, s.f, s.line[1][idx], lane);
-        ++idx;
-        if ((ATE_LOW >> i) & 1) {
-            if (!skip0) wmul_line(s, s.f, s.f, s.line[0][idx], lane);
-            if (!skip1) wmul_line(s, s.f, s.f, s.line[1][idx], lane);
-            ++idx;
-        }
+        wmul(s, s.f, s.f, s.line[idx++], lane);
+        if ((ATE_LOW >> i) & 1) wmul(s, s.f, s.f, s.line[idx++], lane);
     }
-    for (int t = 0; t < 2; ++t, ++idx) {
-        if (!skip0) wmul_line(s, s.f, s.f, s.line[0][idx], lane);
-        if (!skip1) wmul_line(s, s.f, s.f, s.line[1][idx], lane);
-    }
+    wmul(s, s.f, s.f, s.line[idx++], lane);
+    wmul(s, s.f, s.f, s.line[idx++], lane);
     // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
     if (lane == 0) winv_lane0(s.t0, s.f);
     __syncthreads();

@@ -287,7 +287,9 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
             case OP_INV: {
                 Fr v = slot_load(a.slots, in.a, n, p);
                 if (v.is_zero()) atomicCAS(&a.status[p], 0, H2V_ERR_REFERENCE_PANIC);
-                slot_store(a.slots, in.d, n, p, v.inv());
+                // all lanes invert at once: the fixed-exponent chain is uniform across the wave, unlike the data-dependent
+                // steps of the binary-GCD inverse, which a lone lane (affine conversion, pairing) prefers
+                slot_store(a.slots, in.d, n, p, v.inv_fermat());
                 break;
             }
             case OP_POW: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p).pow_u32(in.b)); break;
