@@ -86,20 +86,19 @@ template <class PR> struct Fp {
         }
         return true;
     }
+    // carry chains written with __builtin_addc / __builtin_subc so that they lower to v_add_co / v_addc_co (one
+    // instruction per limb) instead of 64-bit adds and shifts: an Fq addition is ~24 instructions, not ~130
     H2V_HD static uint32_t sub_p(uint32_t r[8], const uint32_t a[8]) {
-        uint32_t borrow = 0;
+        unsigned borrow = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint64_t t = (uint64_t)a[i] - PR::P(i) - borrow;
-            r[i] = (uint32_t)t; borrow = (uint32_t)(t >> 32) & 1;
-        }
+        for (int i = 0; i < 8; ++i) r[i] = __builtin_subc(a[i], PR::P(i), borrow, &borrow);
         return borrow;
     }
 
     H2V_HD Fp operator+(const Fp& b) const {
-        uint32_t t[8]; uint32_t carry = 0;
+        uint32_t t[8]; unsigned carry = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { uint64_t s = (uint64_t)v[i] + b.v[i] + carry; t[i] = (uint32_t)s; carry = (uint32_t)(s >> 32); }
+        for (int i = 0; i < 8; ++i) t[i] = __builtin_addc(v[i], b.v[i], carry, &carry);
         // p < 2^254: a + b < 2^255, no carry out of limb 7
         uint32_t u[8]; uint32_t borrow = sub_p(u, t);
         Fp r;
@@ -108,12 +107,13 @@ template <class PR> struct Fp {
         return r;
     }
     H2V_HD Fp operator-(const Fp& b) const {
-        uint32_t t[8]; uint32_t borrow = 0;
+        uint32_t t[8]; unsigned borrow = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { uint64_t s = (uint64_t)v[i] - b.v[i] - borrow; t[i] = (uint32_t)s; borrow = (uint32_t)(s >> 32) & 1; }
-        uint32_t carry = 0; Fp r;
+        for (int i = 0; i < 8; ++i) t[i] = __builtin_subc(v[i], b.v[i], borrow, &borrow);
+        unsigned carry = 0; Fp r;
+        const uint32_t mask = borrow ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { uint64_t s = (uint64_t)t[i] + (borrow ? PR::P(i) : 0u) + carry; r.v[i] = (uint32_t)s; carry = (uint32_t)(s >> 32); }
+        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_addc(t[i], PR::P(i) & mask, carry, &carry);
         return r;
     }
     H2V_HD Fp neg() const { return zero() - *this; }
