@@ -71,7 +71,6 @@ template <class PR> struct Fp {
     H2V_HD static Fp zero() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = 0; return r; }
     H2V_HD static Fp one() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::ONE(i); return r; }
     H2V_HD static Fp r2() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::R2(i); return r; }
-    H2V_HD static Fp modulus_raw() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::P(i); return r; }
 
     H2V_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= v[i]; return o == 0; }
     H2V_HD bool operator==(const Fp& b) const { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= v[i] ^ b.v[i]; return o == 0; }
@@ -261,12 +260,6 @@ template <class PR> struct Fp {
         return mul(t, r3);
     }
     H2V_HD bool is_odd() const { uint32_t raw[8]; to_raw(raw); return raw[0] & 1; }
-    // numeric order of canonical values: -1, 0, 1
-    H2V_HD static int cmp(const Fp& a, const Fp& b) {
-        uint32_t x[8], y[8]; a.to_raw(x); b.to_raw(y);
-        for (int i = 7; i >= 0; --i) { if (x[i] < y[i]) return -1; if (x[i] > y[i]) return 1; }
-        return 0;
-    }
 };
 
 typedef Fp<FqParams> Fq;

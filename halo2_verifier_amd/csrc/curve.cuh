@@ -102,16 +102,6 @@ H2V_FN G1A g1_to_affine(const G1J& p) {
     return a;
 }
 
-// k * P for a small unsigned k (wave-uniform or per-lane; used in the window reduction)
-H2V_HD G1J g1_mul_u32(const G1J& p, uint32_t k) {
-    G1J r = G1J::identity();
-    for (int i = 31; i >= 0; --i) {
-        r = g1_dbl(r);
-        if ((k >> i) & 1) r = g1_add(r, p);
-    }
-    return r;
-}
-
 // sqrt in Fq for p = 3 mod 4: a^((p+1)/4); caller checks r^2 == a
 H2V_FN Fq fq_sqrt_candidate(const Fq& a) {
     // (p+1)/4 = 0x0c19139cb84c680a6e14116da060561765e05aa45a1c72a34f082305b61f3f52

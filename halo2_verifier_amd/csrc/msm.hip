@@ -36,7 +36,7 @@
 namespace h2v {
 
 #define MSM_HEAVY 40u
-#define MSM_WIN_THREADS 128
+#define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
 MsmPlan msm_plan(uint32_t n) {
@@ -319,7 +319,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, s, ws.counts, ws.offsets, ws.cursor, nb);
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(256), 0, s, pr, p, ws.counts, ws.offsets, ws.cursor, ws.list);
     hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
-    hipLaunchKernelGGL(msm_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
+    hipLaunchKernelGGL(msm_heavy, dim3(64), dim3(MSM_HEAVY_THREADS), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_window, dim3(p.windows, pr.count), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
     hipLaunchKernelGGL(msm_final, dim3((pr.count + 63) / 64), dim3(64), 0, s, ws.window_sums, pr, p);
     H2V_HIP_CHECK(hipGetLastError());

@@ -7,8 +7,11 @@
 //
 // Replaces what the reference obtains from halo2curves at poly/kzg/msm.rs:185-203:
 //   G2Prepared::from(s_g2), G2Prepared::from(-g2)            -> g2_prepare()   (host, once per context)
-//   multi_miller_loop(&[(left, ..), (right, ..)])             -> miller_loop_2()
-//   .final_exponentiation().is_identity()                     -> final_exp_is_one()
+//   multi_miller_loop(&[(left, ..), (right, ..)]).final_exponentiation().is_identity()
+//                                                             -> k_pairing_wave (pairing.hip), which works on the
+//                                                                flat Fq2[w]/(w^6 - xi) view of Fq12 spread over a wave;
+//                                                                the tower below serves g2_prepare and the one Fq12
+//                                                                inversion of the final exponentiation
 // Only the boolean is observable through the reference API, so the line-function
 // normalisation and the exponent multiple used in the hard part are free choices.
 #pragma once
@@ -59,15 +62,6 @@ struct Fq6 {
         Fq2 t2 = (c0 + c2) * (o.c0 + o.c2) - a - c + b;
         return {t0, t1, t2};
     }
-    // (c0 + c1 v + c2 v^2) * (d0 + d1 v)
-    H2V_HD Fq6 mul_by_01(const Fq2& d0, const Fq2& d1) const {
-        Fq2 a = c0 * d0, b = c1 * d1;
-        Fq2 t0 = ((c1 + c2) * d1 - b).mul_xi() + a;
-        Fq2 t1 = (c0 + c1) * (d0 + d1) - a - b;
-        Fq2 t2 = (c0 + c2) * d0 - a + b;
-        return {t0, t1, t2};
-    }
-    H2V_HD Fq6 scale2(const Fq2& k) const { return {c0 * k, c1 * k, c2 * k}; }
     H2V_HD Fq6 mul_v() const { return {c2.mul_xi(), c0, c1}; }
     H2V_FN Fq6 inv() const {
         Fq2 A = c0.sqr() - (c1 * c2).mul_xi();
@@ -93,53 +87,10 @@ struct Fq12 {
         Fq6 a = c0 * o.c0, b = c1 * o.c1;
         return {a + b.mul_v(), (c0 + c1) * (o.c0 + o.c1) - a - b};
     }
-    H2V_FN Fq12 sqr() const {  // complex squaring: 2 Fq6 multiplications
-        Fq6 ab = c0 * c1;
-        Fq6 t = (c0 + c1) * (c0 + c1.mul_v()) - ab - ab.mul_v();
-        return {t, ab + ab};
-    }
-    // Granger-Scott squaring, valid in the cyclotomic subgroup (after the easy part of the final exponentiation):
-    // 6 Fq2 products instead of 12
-    H2V_FN Fq12 cyclotomic_sqr() const {
-        const Fq2 &r0 = c0.c0, &r4 = c0.c1, &r3 = c0.c2, &r2 = c1.c0, &r1 = c1.c1, &r5 = c1.c2;
-        Fq2 tmp = r0 * r1;
-        Fq2 t0 = (r0 + r1) * (r1.mul_xi() + r0) - tmp - tmp.mul_xi(), t1 = tmp.dbl();
-        tmp = r2 * r3;
-        Fq2 t2 = (r2 + r3) * (r3.mul_xi() + r2) - tmp - tmp.mul_xi(), t3 = tmp.dbl();
-        tmp = r4 * r5;
-        Fq2 t4 = (r4 + r5) * (r5.mul_xi() + r4) - tmp - tmp.mul_xi(), t5 = tmp.dbl();
-        Fq12 r;
-        r.c0.c0 = (t0 - r0).dbl() + t0;
-        r.c1.c1 = (t1 + r1).dbl() + t1;
-        Fq2 x5 = t5.mul_xi();
-        r.c1.c0 = (x5 + r2).dbl() + x5;
-        r.c0.c2 = (t4 - r3).dbl() + t4;
-        r.c0.c1 = (t2 - r4).dbl() + t2;
-        r.c1.c2 = (t3 + r5).dbl() + t3;
-        return r;
-    }
     H2V_HD Fq12 conj() const { return {c0, c1.neg()}; }
     H2V_FN Fq12 inv() const {
         Fq6 t = (c0 * c0 - (c1 * c1).mul_v()).inv();
         return {c0 * t, (c1 * t).neg()};
-    }
-    H2V_HD bool is_one() const { return c0 == Fq6::one() && c1 == Fq6::zero(); }
-    // multiply by the sparse line value  l = a + (b + c v) w   (a, b, c in Fq2)
-    H2V_FN Fq12 mul_by_034(const Fq2& a, const Fq2& b, const Fq2& c) const {
-        Fq6 t0 = c0.scale2(a);
-        Fq6 t1 = c1.mul_by_01(b, c);
-        Fq6 s = (c0 + c1).mul_by_01(a + b, c);
-        return {t0 + t1.mul_v(), s - t0 - t1};
-    }
-    H2V_FN Fq12 frob(const PairingConsts& k) const {
-        Fq12 r;
-        r.c0.c0 = c0.c0.conj();
-        r.c1.c0 = c1.c0.conj() * k.gamma1[1];
-        r.c0.c1 = c0.c1.conj() * k.gamma1[2];
-        r.c1.c1 = c1.c1.conj() * k.gamma1[3];
-        r.c0.c2 = c0.c2.conj() * k.gamma1[4];
-        r.c1.c2 = c1.c2.conj() * k.gamma1[5];
-        return r;
     }
 };
 
@@ -148,7 +99,7 @@ struct LineCoeff { Fq2 a, b, c; };  // value at P = (xP, yP):  a * yP  +  (b * x
 
 static constexpr uint64_t BN_X = 4965661367192848881ULL;
 static constexpr uint64_t ATE_LOW = 0x9d797039be763ba8ULL;  // 6x+2 = 2^64 + ATE_LOW
-static constexpr int MAX_LINE_COEFFS = 64 + 64 + 2;
+static constexpr int MAX_LINE_COEFFS = 64 + 64 + 2;  // >= 64 doublings + popcount(ATE_LOW) additions + 2
 
 struct G2Hom { Fq2 x, y, z; };
 
@@ -188,64 +139,6 @@ H2V_FN int g2_prepare(const G2A& q, const PairingConsts& k, LineCoeff* out) {
     out[n++] = g2_add_step(r, q1x, q1y);
     out[n++] = g2_add_step(r, q2x, q2y);
     return n;
-}
-
-// f = prod over two (P_k, prepared Q_k) pairs.  An identity P_k contributes 1.
-H2V_FN Fq12 miller_loop_2(const G1A& p0, const LineCoeff* l0, const G1A& p1, const LineCoeff* l1) {
-    Fq12 f = Fq12::one();
-    bool s0 = p0.is_identity(), s1 = p1.is_identity();
-    int idx = 0;
-    for (int i = 63; i >= 0; --i) {
-        f = f.sqr();
-        if (!s0) f = f.mul_by_034(l0[idx].a.scale(p0.y), l0[idx].b.scale(p0.x), l0[idx].c);
-        if (!s1) f = f.mul_by_034(l1[idx].a.scale(p1.y), l1[idx].b.scale(p1.x), l1[idx].c);
-        ++idx;
-        if ((ATE_LOW >> i) & 1) {
-            if (!s0) f = f.mul_by_034(l0[idx].a.scale(p0.y), l0[idx].b.scale(p0.x), l0[idx].c);
-            if (!s1) f = f.mul_by_034(l1[idx].a.scale(p1.y), l1[idx].b.scale(p1.x), l1[idx].c);
-            ++idx;
-        }
-    }
-    for (int t = 0; t < 2; ++t, ++idx) {
-        if (!s0) f = f.mul_by_034(l0[idx].a.scale(p0.y), l0[idx].b.scale(p0.x), l0[idx].c);
-        if (!s1) f = f.mul_by_034(l1[idx].a.scale(p1.y), l1[idx].b.scale(p1.x), l1[idx].c);
-    }
-    return f;
-}
-
-H2V_FN Fq12 fq12_pow_x(const Fq12& a) {
-    Fq12 r = a;  // BN_X has its top bit at position 62; only called on cyclotomic-subgroup elements
-    for (int i = 61; i >= 0; --i) {
-        r = r.cyclotomic_sqr();
-        if ((BN_X >> i) & 1) r = r * a;
-    }
-    return r;
-}
-
-// final_exponentiation(f).is_identity()
-H2V_FN bool final_exp_is_one(const Fq12& f, const PairingConsts& k) {
-    Fq12 r = f.conj() * f.inv();
-    r = r.frob(k).frob(k) * r;
-    Fq12 y0 = fq12_pow_x(r).conj();
-    Fq12 y1 = y0.cyclotomic_sqr();
-    Fq12 y2 = y1.cyclotomic_sqr();
-    Fq12 y3 = y2 * y1;
-    Fq12 y4 = fq12_pow_x(y3).conj();
-    Fq12 y5 = y4.cyclotomic_sqr();
-    Fq12 y6 = fq12_pow_x(y5).conj();
-    y3 = y3.conj();
-    y6 = y6.conj();
-    Fq12 y7 = y6 * y4;
-    Fq12 y8 = y7 * y3;
-    Fq12 y9 = y8 * y1;
-    Fq12 y10 = y8 * y4;
-    Fq12 y11 = y10 * r;
-    Fq12 y12 = y9.frob(k);
-    Fq12 y13 = y12 * y11;
-    y8 = y8.frob(k).frob(k);
-    Fq12 y14 = y8 * y13;
-    Fq12 y15 = (r.conj() * y9).frob(k).frob(k).frob(k);
-    return (y15 * y14).is_one();
 }
 
 }  // namespace h2v

@@ -28,7 +28,7 @@ struct WaveShared {
     // evaluated at their point) are written here first, then replaced in place by their 6-coefficient product.
     Fq2 line[N_LINES][6];
     Fq2 prod[36];
-    Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6], L[6];
+    Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6];
 };
 
 // dst = x * y in Fq2[w]/(w^6 - xi); dst may alias x or y
@@ -40,25 +40,6 @@ __device__ __forceinline__ void wmul(WaveShared& s, Fq2* dst, const Fq2* x, cons
         for (uint32_t i = 0; i < 6; ++i) {
             if (i <= lane) lo = lo + s.prod[i * 6 + (lane - i)];
             else hi = hi + s.prod[i * 6 + (lane + 6 - i)];
-        }
-        dst[lane] = lo + hi.mul_xi();
-    }
-    __syncthreads();
-}
-// multiply by a line: only the w^0, w^1, w^3 coefficients of y are non-zero
-__device__ __forceinline__ void wmul_line(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* l3, uint32_t lane) {
-    if (lane < 18) {
-        const uint32_t i = lane / 3, jj = lane % 3, j = jj == 2 ? 3 : jj;
-        s.prod[i * 6 + j] = Fq2::mul(x[i], l3[jj]);
-    }
-    __syncthreads();
-    if (lane < 6) {
-        Fq2 lo = Fq2::zero(), hi = Fq2::zero();
-        for (uint32_t i = 0; i < 6; ++i) {
-            uint32_t j = i <= lane ? lane - i : lane + 6 - i;
-            if (j != 0 && j != 1 && j != 3) continue;
-            if (i <= lane) lo = lo + s.prod[i * 6 + j];
-            else hi = hi + s.prod[i * 6 + j];
         }
         dst[lane] = lo + hi.mul_xi();
     }
@@ -138,7 +119,7 @@ __global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pai
     wfrob(s.t0, s.r, consts, lane);
     wfrob(s.t0, s.t0, consts, lane);
     wmul(s, s.r, s.t0, s.r, lane);             // ^(p^2 + 1)
-    // hard part (same chain as final_exp_is_one in pairing.cuh)
+    // hard part: the x-power chain of Fuentes-Castaneda et al. (y0 .. y16)
     Fq2 *y0 = s.t0, *y1 = s.t1, *y3 = s.t2, *y4 = s.t3, *y6 = s.t4, *u = s.t5, *v = s.t6;
     wpow_x(s, y0, s.r, lane); wconj(y0, y0, lane);               // y0 = r^-x
     wmul(s, y1, y0, y0, lane);                                   // y1 = y0^2

@@ -1,0 +1,47 @@
+//! `extern "C"` binding of include/h2v.h for the halo2_verifier crate (feature "mi355x", needs std + the HIP runtime).
+//! UNCOMPILED in this repository: the build image has no Rust toolchain.  The tested callers of the same ABI are
+//! halo2_verifier_amd/verifier.py and bench.py (ctypes).  See INTEGRATION.md.
+#![allow(non_camel_case_types)]
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct h2v_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct h2v_batch { _p: [u8; 0] }
+#[repr(C)] pub struct h2v_options { pub multiopen: c_int, pub transcript: c_int }
+
+pub const H2V_SERDE_PROCESSED: c_int = 0;
+pub const H2V_SERDE_RAW_BYTES: c_int = 1;
+pub const H2V_MULTIOPEN_SHPLONK: c_int = 0;
+pub const H2V_MULTIOPEN_GWC: c_int = 1;
+pub const H2V_TRANSCRIPT_BLAKE2B: c_int = 0;
+pub const H2V_TRANSCRIPT_KECCAK256: c_int = 1;
+
+#[link(name = "h2v_amd")]
+extern "C" {
+    pub fn h2v_device_count() -> c_int;
+    pub fn h2v_last_error() -> *const c_char;
+    pub fn h2v_ctx_create(params: *const u8, params_len: usize, params_format: c_int, vk: *const u8, vk_len: usize, vk_format: c_int,
+                          device: c_int, out: *mut *mut h2v_ctx) -> c_int;
+    pub fn h2v_ctx_create_ex(params: *const u8, params_len: usize, params_format: c_int, vk: *const u8, vk_len: usize, vk_format: c_int,
+                             device: c_int, options: *const h2v_options, out: *mut *mut h2v_ctx) -> c_int;
+    pub fn h2v_ctx_destroy(ctx: *mut h2v_ctx);
+    pub fn h2v_ctx_proof_shape(ctx: *const h2v_ctx, proof_len: *mut usize, n_points: *mut usize, n_scalars: *mut usize,
+                               n_right_terms: *mut usize, n_instance_columns: *mut usize) -> c_int;
+    pub fn h2v_msm_g1(ctx: *mut h2v_ctx, scalars32: *const u8, bases64: *const u8, n: usize, out_xy: *mut u8, out_is_identity: *mut c_int) -> c_int;
+    pub fn h2v_pairing_check(ctx: *mut h2v_ctx, left_xy: *const u8, right_xy: *const u8, ok: *mut c_int) -> c_int;
+    pub fn h2v_verify_batch(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
+                            instances32: *const *const u8, n_instance_columns: usize, col_lens: *const usize, rand32: *const u8,
+                            per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+    pub fn h2v_verify_each(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
+                           instances32: *const *const u8, n_instance_columns: usize, col_lens: *const usize, per_proof_status: *mut c_int) -> c_int;
+    pub fn h2v_batch_create(ctx: *mut h2v_ctx, max_proofs: usize, max_instance_values_per_proof: usize, out: *mut *mut h2v_batch) -> c_int;
+    pub fn h2v_batch_destroy(b: *mut h2v_batch);
+    pub fn h2v_batch_upload(b: *mut h2v_batch, n: usize, proofs_flat: *const u8, proof_len: usize, instances_flat: *const u8,
+                            n_instance_columns: usize, col_lens: *const usize, rand32_tail: *const u8, n_tail: usize) -> c_int;
+    pub fn h2v_batch_launch(b: *mut h2v_batch, with_pairing: c_int) -> c_int;
+    pub fn h2v_batch_finish(b: *mut h2v_batch, per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+    pub fn h2v_batch_export_accumulators(b: *mut h2v_batch, device_dst: *mut c_void) -> c_int;
+    pub fn h2v_batch_fold_check_enqueue(b: *mut h2v_batch, device_accumulators: *const c_void, n_parts: usize) -> c_int;
+    pub fn h2v_batch_set_stream(b: *mut h2v_batch, hip_stream: *mut c_void) -> c_int;
+    pub fn h2v_fold_check(ctx: *mut h2v_ctx, device_accumulators: *const c_void, n_parts: usize, ok: *mut c_int,
+                          out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+}
