@@ -1,0 +1,146 @@
+"""Edge cases of the C ABI on the GPU: object reuse, batches in flight concurrently, instance shapes, serde formats,
+misuse and limits.  Expected values come from the CPU oracle."""
+import ctypes
+import random
+
+import pytest
+
+import circuits
+from circuits import R_MOD
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(s, **kw):
+    import halo2_verifier_amd as h2v
+    return h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes), **kw)
+
+
+def _flat(P, I):
+    return b"".join(P), b"".join(b"".join(col) for i in I for col in i)
+
+
+def test_batches_in_flight_do_not_interfere_and_objects_are_reusable():
+    import halo2_verifier_amd as h2v
+    s = circuits.setup_vector_mul(8, 8)
+    ctx = _ctx(s)
+    P, I = circuits.prove_vector_mul_batch(s, 96, seed=31, threads=8)
+    rnd = random.Random(3)
+    jobs = []
+    for j in range(8):                      # 8 different sub-batches of different sizes
+        lo, n = 7 * j, 5 + 3 * j
+        rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+        jobs.append((P[lo:lo + n], I[lo:lo + n], rand))
+    expected = [circuits.oracle_verify_batch(s, p, i, r) for p, i, r in jobs]
+    batches = [h2v.Batch(ctx, 64, 8) for _ in jobs]
+    for rep in range(3):                    # reuse every batch object three times, all launched before any is finished
+        order = list(range(8))
+        random.Random(rep).shuffle(order)
+        for j in order:
+            p, i, r = jobs[(j + rep) % 8]
+            pf, inf = _flat(p, i)
+            batches[j].upload(pf, 1024, inf, [8], b"".join(x.to_bytes(32, "little") for x in r))
+            batches[j].launch(True)
+        for j in reversed(order):
+            assert batches[j].finish() == expected[(j + rep) % 8]
+    # an empty upload on a used object
+    batches[0].upload(b"", 1024, b"", [8], b"")
+    batches[0].launch(True)
+    ok, st, left, right = batches[0].finish()
+    assert ok is True and st == [] and left == bytes(64) and right == bytes(64)
+    for b in batches:
+        b.close()
+    ctx.close(); s.free()
+
+
+@pytest.mark.parametrize("n_pub", [1, 3, 64])
+def test_instance_lengths(n_pub):
+    s = circuits.setup_vector_mul(9, n_pub)
+    ctx = _ctx(s)
+    P, I = circuits.prove_vector_mul_batch(s, 5, seed=n_pub, threads=4)
+    rand = [11, 12, 13, 14, 15]
+    got = ctx.verify_batch(P, I, rand)
+    assert got == circuits.oracle_verify_batch(s, P, I, rand) and got[0] is True
+    rc_o, g_o = circuits.oracle_guard(s, P[0], I[0])
+    rc_g, g_g = ctx.guard_msm(P[0], I[0])
+    assert rc_o == rc_g == 0 and g_g["challenges"] == g_o["challenges"] and g_g["right_scalars"] == g_o["right_scalars"]
+    ctx.close(); s.free()
+
+
+def test_processed_serde_format_inputs():
+    """VK and params in SerdeFormat::Processed (compressed points, canonical scalars) give the same context."""
+    import halo2_verifier_amd as h2v
+    import oracle_lib
+    L = oracle_lib.load()
+    s = circuits.setup_wide(8, A=8, F=5, L_=1, Sh=1, deg=3)
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = L.h2o_params_convert(s.params, len(s.params), 1, 0, buf, len(buf)); p_proc = buf.raw[:n]
+    n = L.h2o_vk_convert(s.vk, len(s.vk), 1, 0, buf, len(buf)); v_proc = buf.raw[:n]
+    assert len(p_proc) == 164
+    good, inst = circuits.prove_wide(s, witness_seed=3)
+    ref = circuits.oracle_verify_batch(s, [good, good], [inst, inst], [5, 6])
+    for pf, vf, pb, vb in ((0, 0, p_proc, v_proc), (2, 2, s.params, s.vk), (0, 1, p_proc, s.vk)):
+        ctx = h2v.Context(h2v.ParamsKZG(pb, h2v.SerdeFormat(pf)), h2v.VerifyingKey(vb, h2v.SerdeFormat(vf)))
+        assert ctx.verify_batch([good, good], [inst, inst], [5, 6]) == ref
+        ctx.close()
+    with pytest.raises(h2v.H2VError) as e:   # truncated VK
+        h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk[:-7], h2v.SerdeFormat.RawBytes))
+    assert e.value.code == -17
+    with pytest.raises(h2v.H2VError) as e:   # params whose g is not on the curve
+        bad = bytearray(s.params); bad[10] ^= 1
+        h2v.Context(h2v.ParamsKZG(bytes(bad), h2v.SerdeFormat.RawBytes))
+    assert e.value.code == -17
+    s.free()
+
+
+def test_misuse_and_limits():
+    import halo2_verifier_amd as h2v
+    s = circuits.setup_vector_mul(8, 8)
+    ctx = _ctx(s)
+    proof, inst = circuits.prove_vector_mul(s, [2] * 8, [3] * 8)
+    b = h2v.Batch(ctx, 4, 8)
+    with pytest.raises(h2v.H2VError):
+        b.launch(True)                                        # nothing uploaded
+    with pytest.raises(h2v.H2VError):
+        b.finish()                                            # nothing launched
+    pf, inf = _flat([proof] * 5, [inst] * 5)
+    with pytest.raises(h2v.H2VError) as e:
+        b.upload(pf, 1024, inf, [8], None)                    # exceeds the capacity given at creation
+    assert e.value.code == -16
+    with pytest.raises(h2v.H2VError) as e:
+        ctx.verify_batch([proof], [inst], [R_MOD])            # a draw that is not a canonical scalar
+    assert e.value.code == -16
+    with pytest.raises(h2v.H2VError) as e:                    # 5000 public inputs: Error::InstanceTooLarge
+        ctx.verify_batch([proof], [[[circuits.le32(1)] * 5000]], [1])
+    assert e.value.code == -6
+    with pytest.raises(h2v.H2VError) as e:                    # two instance columns for a one-column VK
+        ctx.verify_batch([proof], [[inst[0], inst[0]]], [1])
+    assert e.value.code == -1
+    with pytest.raises(h2v.H2VError):                         # unknown option
+        _ctx(s, multiopen=7)
+    # a context without a VK serves only the group-level entry points
+    c2 = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes))
+    with pytest.raises(h2v.H2VError):
+        c2.verify_batch([proof], [inst], [1])
+    c2.close(); b.close(); ctx.close(); s.free()
+
+
+def test_reference_strategy_surface():
+    """verify_proof / AccumulatorStrategy / SingleStrategy used the way the reference's callers use them (tests/helpers.rs:66-82)."""
+    import halo2_verifier_amd as h2v
+    s = circuits.setup_vector_mul(8, 10)
+    params, vk = h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes)
+    proof, inst = circuits.prove_vector_mul(s, [2] * 10, [3] * 10)
+    assert h2v.verify_proof(params, vk, h2v.SingleStrategy(params), inst, proof) is None
+    bad = [[circuits.le32(7)] + inst[0][1:]]
+    with pytest.raises(h2v.H2VError) as e:
+        h2v.verify_proof(params, vk, h2v.SingleStrategy(params), bad, proof)
+    assert e.value.code == h2v.PlonkError.ConstraintSystemFailure
+    st = h2v.AccumulatorStrategy(params)
+    for _ in range(3):
+        st = h2v.verify_proof(params, vk, st, inst, proof)
+    assert st.finalize() is True
+    st = h2v.verify_proof(params, vk, h2v.verify_proof(params, vk, h2v.AccumulatorStrategy(params), inst, proof), bad, proof)
+    assert st.finalize() is False
+    assert h2v.AccumulatorStrategy(params).finalize() is True   # empty accumulator
+    s.free()
