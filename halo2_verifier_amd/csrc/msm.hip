@@ -14,7 +14,7 @@
 //   2. msm_scan     exclusive prefix sum of the histogram (one workgroup)
 //   3. msm_scatter  one lane per term: counting-sort term indices into per-bucket lists
 //   4. msm_bucket   one lane per bucket: mixed Jacobian+affine additions over its list;
-//                   buckets with more than max(64, 4 x average) entries are handed to
+//                   buckets with more than max(64, 2 x average) entries are handed to
 //      msm_heavy    one workgroup per heavy bucket: strided partial sums + LDS tree.  (The top window of
 //                   a 254-bit scalar is only a few bits wide, so its few buckets each collect n/2^bits
 //                   terms — without this a single lane serialises hundreds of additions.)
@@ -35,7 +35,7 @@
 
 namespace h2v {
 
-#define MSM_HEAVY_MIN 64u   // a bucket is 'heavy' when it holds more than max(this, 4 x the average) entries
+#define MSM_HEAVY_MIN 64u   // a bucket is 'heavy' when it holds more than max(this, 2 x the average) entries
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
@@ -318,10 +318,11 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(256), 0, s, pr, p, ws.counts, ws.offsets, ws.cursor, ws.list);
     hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, s, ws.counts, ws.offsets, ws.cursor, nb);
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(256), 0, s, pr, p, ws.counts, ws.offsets, ws.cursor, ws.list);
-    // with random scalars a bucket holds about 2n / buckets entries; only outliers (skewed inputs) go to the workgroup path
-    uint32_t heavy_threshold = std::max<uint32_t>(MSM_HEAVY_MIN, 4u * (uint32_t)((2ull * nmax + p.buckets - 1) / p.buckets));
+    // with random scalars a bucket holds about 2n / buckets entries; outliers go to the workgroup path: skewed inputs, and the
+    // top window, whose digits span fewer bits (128 is not a multiple of c) so that its buckets collect several times the average
+    uint32_t heavy_threshold = std::max<uint32_t>(MSM_HEAVY_MIN, 2u * (uint32_t)((2ull * nmax + p.buckets - 1) / p.buckets));
     hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb, heavy_threshold);
-    hipLaunchKernelGGL(msm_heavy, dim3(64), dim3(MSM_HEAVY_THREADS), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
+    hipLaunchKernelGGL(msm_heavy, dim3(512), dim3(MSM_HEAVY_THREADS), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_window, dim3(p.windows, pr.count), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
     hipLaunchKernelGGL(msm_final, dim3((pr.count + 63) / 64), dim3(64), 0, s, ws.window_sums, pr, p);
     H2V_HIP_CHECK(hipGetLastError());
