@@ -14,6 +14,7 @@ achieved = 96 B x terms / mean MSM-stage time measured with HIP events on the ba
 timed on a bounded sample of the same proofs on this host.
 """
 import argparse
+import math
 import ctypes
 import json
 import os
@@ -82,7 +83,8 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--depth", type=int, default=32, help="batches in flight per GPU")
+    ap.add_argument("--groups", type=int, default=8, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups)")
+    ap.add_argument("--depth", type=int, default=8, help="launches in flight per GPU (one HIP stream each)")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,27 +123,36 @@ def main():
     if rank != 0:
         d = load_or_make_proofs(args.distinct, K_CIRCUIT, log)
 
+    # A step is one batch of B proofs per GPU with its own accumulators and its own pairing (AccumulatorStrategy).  One launch
+    # carries G steps side by side (a grouped batch): every kernel runs once for all G, each group keeps its own verdict.
     B = args.batch
+    G = math.gcd(max(1, args.groups), args.steps)   # exactly --steps timed steps
+    launches = args.steps // G
+    warm_launches = (args.warmup + G - 1) // G
     reps = (B + args.distinct - 1) // args.distinct
-    proofs_flat = (d["proofs"] * reps)[: B * 1024]
-    inst_flat = (d["inst"] * reps)[: B * 32 * N_PUBLIC]
+    proofs_flat = (d["proofs"] * reps)[: B * 1024] * G
+    inst_flat = (d["inst"] * reps)[: B * 32 * N_PUBLIC] * G
     total = B * world
-    # one seeded stream of Fr::random draws for the whole (N x batch) step, indexed by global proof id
-    rand_all = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567) % (1 << 250)).to_bytes(32, "little") for i in range(1, total + 1))
     lo, hi = h2d.shard_bounds(total, world, rank)
-    tail = h2d.tail_for_shard(rand_all, lo)
+    # per group one seeded stream of Fr::random draws for the whole (N x batch) step, indexed by global proof id; a rank
+    # uploads, for every group, the draws from its first proof to the end of the step (the multiplier of a proof is the
+    # product of the draws of all later proofs of its step)
+    tail = b""
+    for g in range(G):
+        rand_all = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567 + g * 0x51ed27) % (1 << 250)).to_bytes(32, "little") for i in range(1, total + 1))
+        tail += h2d.tail_for_shard(rand_all, lo)
 
     ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes), device=local_rank)
     shape = ctx.proof_shape()
-    depth = max(1, min(args.depth, args.steps))
+    depth = max(1, min(args.depth, launches))
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)]
     batches = []
     for s in streams:
-        b = h2v.Batch(ctx, B, N_PUBLIC, stream=s.cuda_stream)
+        b = h2v.Batch(ctx, B * G, N_PUBLIC, stream=s.cuda_stream, groups=G)
         b.upload(proofs_flat, 1024, inst_flat, [N_PUBLIC], tail)   # resident in HBM before the timed region
         b.set_profiling(True)
         batches.append(b)
-    acc_local = [torch.empty(h2d.ACC_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(depth)]
+    acc_local = [torch.empty(h2d.ACC_BYTES * G, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(depth)]
     gathered = [None] * depth
     in_flight = [False] * depth
     stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
@@ -150,9 +161,9 @@ def main():
 
     def retire(i, timed):
         nonlocal stage_cnt
-        ok, st, left, right = batches[i].finish()
+        ok, st, left, right = batches[i].finish_groups()
         in_flight[i] = False
-        if not ok or any(st):
+        if not all(ok) or any(st):
             raise SystemExit(f"verification failed inside the benchmark: ok={ok}")
         if timed:
             for k2, v in batches[i].timings_ms().items():
@@ -168,8 +179,8 @@ def main():
             with torch.cuda.stream(streams[i]):
                 b.launch(with_pairing=False)
                 b.export_accumulators(acc_local[i].data_ptr())
-                gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of 192 B per rank
-                b.fold_check_enqueue(gathered[i].data_ptr(), world)          # fold + the ONE pairing for the whole step
+                gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 192 B per rank
+                b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
         in_flight[i] = True
 
     def run(nsteps, timed):
@@ -182,13 +193,13 @@ def main():
             if in_flight[i]:
                 retire(i, timed)
 
-    run(args.warmup, False)
+    run(warm_launches, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, True)
+    run(launches, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -205,7 +216,7 @@ def main():
         # terms of one launch: every point slot of every local proof (right channel) + the VK-wide bases folded
         # over the batch (fixed + permutation commitments + g) + one h2 term per proof (left channel)
         n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
-        terms_total = n_local * shape["n_points"] + n_shared + n_local
+        terms_total = G * (n_local * shape["n_points"] + n_shared + n_local)
         msm_ms = stages["msm"]
         # HBM traffic of the MSM stage per launch comes from the committed PMC profile of this same workload
         # (separate rocprofv3 --pmc passes cannot run inside the timed region); null if it does not match this shape
@@ -231,10 +242,11 @@ def main():
             "dtype": "u32 limbs (254-bit prime-field integers)",
             "data": "synthetic",
             "config": {"workload": f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
-                                   f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step), {args.distinct} distinct proofs",
-                       "proofs_per_gpu_per_step": B, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
+                                   f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step), {args.distinct} distinct proofs; "
+                                   f"{G} steps per launch (grouped batch), {depth} launches in flight",
+                       "proofs_per_gpu_per_step": B, "steps_per_launch": G, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "MSM stage (msm_count/scan/scatter/bucket/window/final, both channels)", "terms_per_launch": terms_total,
+                         "kernel": "MSM stage (msm_count/scan/scatter/bucket/heavy/window/final, both channels of every step of a launch)", "terms_per_launch": terms_total,
                          "mean_stage_ms": msm_ms},
             "stages_ms": stages,
         }

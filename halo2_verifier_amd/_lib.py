@@ -41,6 +41,8 @@ SIGNATURES = {
     "h2v_batch_upload": (c_int, [c_vp, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_szp, c_u8p, c_sz]),
     "h2v_batch_launch": (c_int, [c_vp, c_int]),
     "h2v_batch_finish": (c_int, [c_vp, c_intp, c_intp, c_u8p, c_u8p]),
+    "h2v_batch_set_groups": (c_int, [c_vp, c_sz]),
+    "h2v_batch_finish_groups": (c_int, [c_vp, c_intp, c_intp, c_u8p, c_u8p, c_sz]),
     "h2v_batch_accumulators": (c_int, [c_vp, ctypes.POINTER(c_vp), c_szp]),
     "h2v_batch_stream": (c_vp, [c_vp]),
     "h2v_batch_set_stream": (c_int, [c_vp, c_vp]),

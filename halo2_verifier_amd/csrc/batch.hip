@@ -18,8 +18,8 @@ template <class T> int dev_alloc(T*& p, size_t count) {
 // (re)allocate the per-batch device workspace for a given plan
 int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     const Plan& pl = pd->host;
-    size_t N = b->max_proofs;
-    size_t sig = (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
+    size_t N = b->max_proofs, G = b->groups;
+    size_t sig = G * 7919u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
     if (b->cap_plan_sig == sig && b->pts) return 0;
     int rc;
     uint32_t words = (uint32_t)((pl.stream.size() + 7) / 8);
@@ -35,15 +35,15 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->chal, (size_t)pl.squeeze_at.size() * N))) return rc;
     if ((rc = dev_alloc(b->mult, N))) return rc;
     if ((rc = dev_alloc(b->slots, (size_t)pl.n_slots * N))) return rc;
-    if ((rc = dev_alloc(b->msm_scal, (N * pl.n_points + pl.n_shared) * 8))) return rc;
+    if ((rc = dev_alloc(b->msm_scal, (N * pl.n_points + G * pl.n_shared) * 8))) return rc;
     if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
     if ((rc = dev_alloc(b->left_scal, N * pl.n_points * 8))) return rc;
-    if ((rc = dev_alloc(b->acc, 2))) return rc;
+    if ((rc = dev_alloc(b->acc, 2 * G))) return rc;
     if ((rc = dev_alloc(b->pairs, 2 * N))) return rc;
-    if ((rc = dev_alloc(b->ok, N))) return rc;
-    if ((rc = dev_alloc(b->out_bytes, 128))) return rc;
-    if ((rc = dev_alloc(b->out_ident, 2))) return rc;
-    if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + pl.n_shared)), 2))) return rc;
+    if ((rc = dev_alloc(b->ok, std::max(N, G)))) return rc;
+    if ((rc = dev_alloc(b->out_bytes, 128 * G))) return rc;
+    if ((rc = dev_alloc(b->out_ident, 2 * G))) return rc;
+    if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + G * pl.n_shared)), (uint32_t)(2 * G), (uint32_t)((N + G - 1) / G * pl.n_points + pl.n_shared)))) return rc;
     b->cap_plan_sig = sig;
     return 0;
 }
@@ -85,6 +85,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     if (proof_len < pl.proof_len) { set_last_error("h2v_batch_upload: proof_len is shorter than this VK's proof"); return H2V_ERR_BAD_ARGUMENT; }
     if (pl.n_instance_values && n && !instances_flat) { set_last_error("h2v_batch_upload: instances missing"); return H2V_ERR_BAD_ARGUMENT; }
     if (rand_tail && n_tail < n) { set_last_error("h2v_batch_upload: n_tail < n"); return H2V_ERR_BAD_ARGUMENT; }
+    if (b->groups > 1 && (n % b->groups || (rand_tail && n_tail % b->groups))) { set_last_error("h2v_batch_upload: n and n_tail must be multiples of the group count"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_buffers(b, pd))) return rc;
     b->plan = pd; b->n = (uint32_t)n; b->launched = false;
@@ -114,6 +115,8 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
     const Plan& pl = pd->host;
     hipStream_t s = b->stream;
     uint32_t n = b->n;
+    const uint32_t G = b->groups, gs = n / G;
+    if (single && G > 1) { set_last_error("a grouped batch cannot run the per-proof (SingleStrategy) path"); return H2V_ERR_BAD_ARGUMENT; }
     b->with_pairing = with_pairing != 0; b->single = single; b->launched = true;
     int rc;
     int ev = 0;
@@ -124,7 +127,7 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
     if ((rc = decompress_stage_enqueue(s, g))) return rc;
     mark();
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
-    if (n) { if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, b->mult))) return rc; }
+    if (n) { if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, G, b->mult))) return rc; }
     mark();
     if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
@@ -138,36 +141,42 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
         mark();
         return 0;
     }
-    if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, b->msm_scal))) return rc; }
+    if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, G, b->msm_scal))) return rc; }
     mark();
-    uint32_t terms = n ? n * pl.n_points + pl.n_shared : 0;
-    {   // both channels in one set of launches: [0] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points), [1] right = pooled
-        // Guard terms + folded VK-wide bases.  Both index the same point array; unused slots have zero scalars and cost nothing.
-        MsmProblems pr; pr.count = 2;
-        pr.p[0] = MsmProblem{b->left_scal, b->pts, b->acc + 0, 8, 1, n * pl.n_points};
-        pr.p[1] = MsmProblem{b->msm_scal, b->pts, b->acc + 1, 8, 1, terms};
+    {   // both channels of every group in one set of launches: [2g] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points),
+        // [2g+1] right = the group's pooled Guard terms + its folded VK-wide bases.  Both index the same point array; unused
+        // slots have zero scalars and cost nothing.
+        MsmProblems pr;
+        const uint32_t np = pl.n_points;
+        for (uint32_t g = 0; g < G; ++g) {
+            const size_t first = (size_t)g * gs * np;
+            pr.p.push_back(MsmProblem(b->left_scal + first * 8, b->pts + first, b->acc + 2 * g, 8, 1, gs * np));
+            pr.p.push_back(MsmProblem(b->msm_scal + first * 8, b->pts + first, b->acc + 2 * g + 1, 8, 1, gs * np,
+                                      b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
+        }
         if ((rc = msm_enqueue_multi(s, b->ws, pr))) return rc;
     }
     mark();
-    if (with_pairing) { if ((rc = pairing_check_enqueue(s, ctx->pairing, b->acc, 1, b->ok))) return rc; }
+    if (with_pairing) { if ((rc = pairing_check_enqueue(s, ctx->pairing, b->acc, G, b->ok))) return rc; }
     mark();
-    if ((rc = point_to_bytes_enqueue(s, b->acc, b->out_bytes, b->out_ident, 2))) return rc;
+    if ((rc = point_to_bytes_enqueue(s, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
     return 0;
 }
 
-int finish_impl(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t* out_left, uint8_t* out_right) {
+// group_ok / out_left / out_right hold one entry (64 bytes) per group
+int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left, uint8_t* out_right) {
     if (!b || !b->launched) { set_last_error("h2v_batch_finish: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     hipStream_t s = b->stream;
-    uint32_t n = b->n;
+    const uint32_t n = b->n, G = b->groups, gs = n / G;
     std::vector<int> st(n ? n : 1, 0);
-    std::vector<uint32_t> okv(b->single ? (n ? n : 1) : 1, 1);
-    uint8_t outb[128]; memset(outb, 0, 128);
+    std::vector<uint32_t> okv(b->single ? (n ? n : 1) : G, 1);
+    std::vector<uint8_t> outb(128 * (size_t)G, 0);
     if (n) H2V_HIP_CHECK(hipMemcpyAsync(st.data(), b->status, sizeof(int) * n, hipMemcpyDeviceToHost, s));
     if (b->single) { if (n) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * n, hipMemcpyDeviceToHost, s)); }
     else {
-        if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4, hipMemcpyDeviceToHost, s));
-        H2V_HIP_CHECK(hipMemcpyAsync(outb, b->out_bytes, 128, hipMemcpyDeviceToHost, s));
+        if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
+        H2V_HIP_CHECK(hipMemcpyAsync(outb.data(), b->out_bytes, 128 * (size_t)G, hipMemcpyDeviceToHost, s));
     }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_last_error(std::string("h2v_batch_finish: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
@@ -178,16 +187,18 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t* out
         hipEventElapsedTime(&t34, b->ev[3], b->ev[4]); hipEventElapsedTime(&t45, b->ev[4], b->ev[5]); hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
         b->last_ms[0] = t01; b->last_ms[1] = t12; b->last_ms[2] = t23; b->last_ms[3] = t34; b->last_ms[4] = t45; b->last_ms[5] = t56;
     }
-    bool all_ok = true;
+    std::vector<char> all_ok(G, 1);
     for (uint32_t i = 0; i < n; ++i) {
         int v = st[i];
         if (b->single && v == 0 && !okv[i]) v = H2V_ERR_CONSTRAINT_SYSTEM_FAILURE;  // kzg/strategy.rs:171-175
         if (per_proof_status) per_proof_status[i] = v;
-        if (v != 0) all_ok = false;
+        if (v != 0) all_ok[i / gs] = 0;
     }
-    if (batch_ok) *batch_ok = b->single ? (all_ok ? 1 : 0) : ((all_ok && (!b->with_pairing || okv[0])) ? 1 : 0);
-    if (out_left) memcpy(out_left, outb, 64);
-    if (out_right) memcpy(out_right, outb + 64, 64);
+    for (uint32_t g = 0; g < G; ++g) {
+        if (group_ok) group_ok[g] = b->single ? (all_ok[g] ? 1 : 0) : ((all_ok[g] && (!b->with_pairing || okv[g])) ? 1 : 0);
+        if (out_left) memcpy(out_left + 64 * (size_t)g, &outb[128 * (size_t)g], 64);
+        if (out_right) memcpy(out_right + 64 * (size_t)g, &outb[128 * (size_t)g + 64], 64);
+    }
     return 0;
 }
 
@@ -288,12 +299,23 @@ int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t 
 }
 int h2v_batch_launch(h2v_batch* b, int with_pairing) { return launch_impl(b, with_pairing, false); }
 int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    if (b && b->groups > 1) { set_last_error("h2v_batch_finish: the batch is grouped, use h2v_batch_finish_groups"); return H2V_ERR_BAD_ARGUMENT; }
     return finish_impl(b, per_proof_status, batch_ok, out_left_xy, out_right_xy);
+}
+int h2v_batch_set_groups(h2v_batch* b, size_t groups) {
+    if (!b || !groups || groups > MSM_MAX_PROBLEMS / 2 || groups > b->max_proofs) { set_last_error("h2v_batch_set_groups: bad group count"); return H2V_ERR_BAD_ARGUMENT; }
+    if (b->stream) hipStreamSynchronize(b->stream);
+    b->groups = (uint32_t)groups; b->launched = false; b->plan = nullptr;  // the next upload re-sizes the workspace
+    return 0;
+}
+int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left_xy, uint8_t* out_right_xy, size_t n_groups) {
+    if (!b || n_groups != b->groups) { set_last_error("h2v_batch_finish_groups: n_groups does not match h2v_batch_set_groups"); return H2V_ERR_BAD_ARGUMENT; }
+    return finish_impl(b, per_proof_status, group_ok, out_left_xy, out_right_xy);
 }
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes) {
     if (!b || !b->acc || !device_ptr) { set_last_error("h2v_batch_accumulators: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
     *device_ptr = b->acc;
-    if (nbytes) *nbytes = 2 * sizeof(G1J);
+    if (nbytes) *nbytes = 2 * sizeof(G1J) * b->groups;
     return 0;
 }
 void* h2v_batch_stream(h2v_batch* b) { return b ? (void*)b->stream : nullptr; }
@@ -308,16 +330,17 @@ int h2v_batch_set_stream(h2v_batch* b, void* hip_stream) {
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst) {
     if (!b || !b->launched || !device_dst) { set_last_error("h2v_batch_export_accumulators: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
-    H2V_HIP_CHECK(hipMemcpyAsync(device_dst, b->acc, 2 * sizeof(G1J), hipMemcpyDeviceToDevice, b->stream));
+    H2V_HIP_CHECK(hipMemcpyAsync(device_dst, b->acc, 2 * sizeof(G1J) * b->groups, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
 int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts) {
     if (!b || !b->launched || !device_accumulators || !n_parts) { set_last_error("h2v_batch_fold_check_enqueue: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     int rc;
-    if ((rc = fold_pairs_enqueue(b->stream, (const G1J*)device_accumulators, (uint32_t)n_parts, b->acc))) return rc;
-    if ((rc = pairing_check_enqueue(b->stream, b->ctx->pairing, b->acc, 1, b->ok))) return rc;
-    if ((rc = point_to_bytes_enqueue(b->stream, b->acc, b->out_bytes, b->out_ident, 2))) return rc;
+    const uint32_t G = b->groups;
+    if ((rc = fold_pairs_enqueue(b->stream, (const G1J*)device_accumulators, (uint32_t)n_parts, b->acc, 2 * G))) return rc;
+    if ((rc = pairing_check_enqueue(b->stream, b->ctx->pairing, b->acc, G, b->ok))) return rc;
+    if ((rc = point_to_bytes_enqueue(b->stream, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
     b->with_pairing = true;
     return 0;
 }

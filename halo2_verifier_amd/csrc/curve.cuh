@@ -61,7 +61,7 @@ __host__ __device__ __forceinline__ G1J g1_add_inl(const G1J& p, const G1J& q) {
     Fq U1 = H2V_M(p.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
     Fq S1 = H2V_M(H2V_M(p.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, p.Z), Z1Z1);
     if (U1 == U2) {
-        if (S1 == S2) return g1_dbl(p);  // (rare) doubling path stays a call
+        if (S1 == S2) { G1J t = p; return g1_dbl(t); }  // rare; a copy is passed so that the caller's accumulator never has its address taken (it stays in registers)
         return G1J::identity();
     }
     Fq H = U2 - U1, H2 = H.dbl(), I = H2V_M(H2, H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
@@ -79,7 +79,7 @@ __host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1
     Fq Z1Z1 = H2V_M(p.Z, p.Z);
     Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, p.Z), Z1Z1);
     if (p.X == U2) {
-        if (p.Y == S2) return g1_dbl(p);
+        if (p.Y == S2) { G1J t = p; return g1_dbl(t); }  // rare; see g1_add_inl
         return G1J::identity();
     }
     Fq H = U2 - p.X, HH = H2V_M(H, H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - p.Y).dbl(), V = H2V_M(p.X, I);
@@ -89,6 +89,39 @@ __host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1
     r.Y = H2V_M(rr, V - r.X) - H2V_M(p.Y, J).dbl();
     r.Z = H2V_M(ZH, ZH) - Z1Z1 - HH;
     return r;
+}
+
+// In-place forms for the hot loops of the MSM kernels.  They return false — leaving the accumulator untouched — in
+// the two degenerate cases (equal or opposite points), which the caller handles on a slow path OUTSIDE its loop: a
+// call inside the loop would take the accumulator's address and force it out of registers into scratch memory.
+__host__ __device__ __forceinline__ bool g1_madd_fast(G1J& acc, const G1A& q) {
+    if (q.is_identity()) return true;
+    if (acc.is_identity()) { acc.X = q.x; acc.Y = q.y; acc.Z = Fq::one(); return true; }
+    Fq Z1Z1 = H2V_M(acc.Z, acc.Z);
+    Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, acc.Z), Z1Z1);
+    if (acc.X == U2) return false;
+    Fq H = U2 - acc.X, HH = H2V_M(H, H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - acc.Y).dbl(), V = H2V_M(acc.X, I);
+    Fq ZH = acc.Z + H;
+    Fq X3 = H2V_M(rr, rr) - J - V.dbl();
+    Fq Y3 = H2V_M(rr, V - X3) - H2V_M(acc.Y, J).dbl();
+    acc.Z = H2V_M(ZH, ZH) - Z1Z1 - HH;
+    acc.X = X3; acc.Y = Y3;
+    return true;
+}
+__host__ __device__ __forceinline__ bool g1_add_fast(G1J& acc, const G1J& q) {
+    if (q.is_identity()) return true;
+    if (acc.is_identity()) { acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z; return true; }
+    Fq Z1Z1 = H2V_M(acc.Z, acc.Z), Z2Z2 = H2V_M(q.Z, q.Z);
+    Fq U1 = H2V_M(acc.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
+    if (U1 == U2) return false;
+    Fq S1 = H2V_M(H2V_M(acc.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, acc.Z), Z1Z1);
+    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_M(H2, H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
+    Fq ZZ = acc.Z + q.Z;
+    Fq X3 = H2V_M(rr, rr) - J - V.dbl();
+    Fq Y3 = H2V_M(rr, V - X3) - H2V_M(S1, J).dbl();
+    acc.Z = H2V_M(H2V_M(ZZ, ZZ) - Z1Z1 - Z2Z2, H);
+    acc.X = X3; acc.Y = Y3;
+    return true;
 }
 
 H2V_FN G1J g1_dbl(const G1J& p) { return g1_dbl_inl(p); }

@@ -29,13 +29,22 @@ struct MsmPlan {
 };
 MsmPlan msm_plan(uint32_t n);
 
-// One MSM of a multi-problem launch: term i reads scalars[i * sstride ..+8) and bases[i * bstride]
+// One MSM of a multi-problem launch: term i < n1 reads scalars[i * sstride ..+8) and bases[i * bstride]; terms n1 <= i < n
+// read a second segment (scalars2, bases2) at index i - n1 (a batch's VK-wide bases live apart from its own points).
 struct MsmProblem {
     const uint32_t* scalars; const G1A* bases; G1J* out;
     uint32_t sstride, bstride, n;
+    uint32_t n1;
+    const uint32_t* scalars2; const G1A* bases2;
+    MsmProblem() : scalars(nullptr), bases(nullptr), out(nullptr), sstride(8), bstride(1), n(0), n1(0), scalars2(nullptr), bases2(nullptr) {}
+    MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n_) : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n_), n1(n_), scalars2(nullptr), bases2(nullptr) {}
+    MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n1_, const uint32_t* s2, const G1A* b2, uint32_t n2)
+        : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n1_ + n2), n1(n1_), scalars2(s2), bases2(b2) {}
 };
-#define MSM_MAX_PROBLEMS 16
-struct MsmProblems { MsmProblem p[MSM_MAX_PROBLEMS]; uint32_t count = 0; };
+#define MSM_MAX_PROBLEMS 256      // per launch (a grouped batch: two channels per group)
+#define MSM_PROBLEM_CHUNK 16      // descriptors handed to the device per setter launch (kernel-argument space)
+struct MsmProblemChunk { MsmProblem p[MSM_PROBLEM_CHUNK]; };
+struct MsmProblems { std::vector<MsmProblem> p; };
 
 struct MsmWorkspace {
     uint32_t cap_terms = 0, cap_problems = 0;
@@ -45,8 +54,10 @@ struct MsmWorkspace {
     uint32_t* list = nullptr;     // term indices sorted by (problem, window, bucket)
     G1J* bucket_pts = nullptr;    // [problems * windows * buckets]
     G1J* window_sums = nullptr;   // [problems * windows]
+    MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight
     size_t cap_buckets = 0, cap_list = 0;
-    int alloc(uint32_t max_total_terms, uint32_t max_problems);
+    // max_terms_per_problem sizes the bucket arrays (the window plan follows the largest problem of a launch)
+    int alloc(uint32_t max_total_terms, uint32_t max_problems, uint32_t max_terms_per_problem = 0);
     void release();
 };
 // Enqueue all problems of `pr` (each: sum_i scalars[i] * bases[i] -> *out, Jacobian, device memory).  Asynchronous on `s`.
@@ -60,7 +71,7 @@ int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, 
 int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
 // Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n);
-// acc[0] = sum of parts[2*i], acc[1] = sum of parts[2*i+1]
-int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc2);
+// acc[k] = sum_i parts[i * width + k] for k < width (width = 2 x groups: left/right of every group)
+int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc, uint32_t width = 2);
 
 }  // namespace h2v

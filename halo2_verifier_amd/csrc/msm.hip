@@ -10,9 +10,11 @@
 //                   recoded into SIGNED c-bit digits, so a 254-bit scalar costs 2*ceil(129/c) bucket entries over
 //                   ceil(129/c) windows of 2^(c-1) buckets (instead of ceil(254/c) windows of 2^c - 1): half the windows
 //                   to reduce and half the doublings in the final Horner chain
-//   1. msm_count    one lane per term: extract every window's digit, histogram (problem,window,bucket)
+//   1. msm_count    one workgroup per tile of 1024 terms: signed digits of both GLV halves, histogram staged in LDS
+//                   (one LDS atomic per entry), one global atomic per non-empty (tile, bucket)
 //   2. msm_scan     exclusive prefix sum of the histogram (one workgroup)
-//   3. msm_scatter  one lane per term: counting-sort term indices into per-bucket lists
+//   3. msm_scatter  same tiles: LDS histogram again, one global atomic per (tile, bucket) reserves the tile's span of
+//                   the bucket's list, LDS atomics hand out positions inside it
 //   4. msm_bucket   one lane per bucket: mixed Jacobian+affine additions over its list;
 //                   buckets with more than max(64, 2 x average) entries are handed to
 //      msm_heavy    one workgroup per heavy bucket: strided partial sums + LDS tree.  (The top window of
@@ -35,7 +37,7 @@
 
 namespace h2v {
 
-#define MSM_HEAVY_MIN 64u   // a bucket is 'heavy' when it holds more than max(this, 2 x the average) entries
+#define MSM_HEAVY_MIN 32u   // a bucket is 'heavy' when it holds more than max(this, 2 x the average) entries
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
@@ -51,12 +53,13 @@ MsmPlan msm_plan(uint32_t n) {
     return best;
 }
 
-int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems) {
+int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_per_problem) {
     release();
     cap_terms = max_terms; cap_problems = max_problems;
+    if (!max_per_problem || max_per_problem > max_terms) max_per_problem = max_terms;
     size_t mb = 0;
-    for (uint32_t n = 1; n <= max_terms; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n); mb = std::max(mb, (size_t)p.windows * p.buckets); }
-    { MsmPlan p = msm_plan(max_terms); mb = std::max(mb, (size_t)p.windows * p.buckets); }
+    for (uint32_t n = 1; n <= max_per_problem; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n); mb = std::max(mb, (size_t)p.windows * p.buckets); }
+    { MsmPlan p = msm_plan(max_per_problem); mb = std::max(mb, (size_t)p.windows * p.buckets); }
     mb *= max_problems;
     cap_buckets = mb; cap_list = (size_t)max_terms * 130;  // c >= 2  =>  2 halves x <= 65 windows; max_terms = total terms over all problems
     H2V_HIP_CHECK(hipMalloc(&counts, (mb + 1) * 4));
@@ -65,6 +68,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems) {
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
     H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1J)));
     H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1J)));
+    H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     return 0;
 }
 void MsmWorkspace::release() {
@@ -74,7 +78,8 @@ void MsmWorkspace::release() {
     if (list) hipFree(list);
     if (bucket_pts) hipFree(bucket_pts);
     if (window_sums) hipFree(window_sums);
-    counts = offsets = cursor = list = nullptr; bucket_pts = window_sums = nullptr;
+    if (problems) hipFree(problems);
+    counts = offsets = cursor = list = nullptr; bucket_pts = window_sums = nullptr; problems = nullptr;
     cap_terms = 0; cap_problems = 0;
 }
 
@@ -149,38 +154,74 @@ __device__ __forceinline__ uint32_t raw_window(const uint32_t m[5], uint32_t w, 
 #define MSM_ENTRY_NEG 0x80000000u
 #define MSM_ENTRY_TERM 0x3fffffffu
 
+// Counting sort, passes 1 and 3.  A workgroup owns a tile of MSM_TILE consecutive terms of one problem and keeps the
+// histogram of (a group of) windows in LDS: every (term, half, window) entry costs one LDS atomic; global atomics
+// are issued once per non-empty bin per tile — for the bench shape ~6x fewer than one global atomic per entry.
+//   count:   LDS histogram -> counts[bin] += h
+//   scatter: LDS histogram -> base = cursor[bin] += h (global, returns the tile's first position inside the bucket)
+//            -> the LDS word becomes a running position -> every entry takes offsets[bin] + (LDS word)++
+#define MSM_TILE 1024u
+#define MSM_TILE_THREADS 256u
+#define MSM_LDS_WORDS 16384u   // 64 KB of histogram per workgroup: as many windows per pass as fit
+
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) msm_count_or_scatter(MsmProblems pr, MsmPlan p, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                            uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
-    uint32_t q = blockIdx.y;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= pr.p[q].n) return;
-    const uint32_t* s = pr.p[q].scalars + (size_t)pr.p[q].sstride * t;
-    uint32_t nz = 0;
-    for (int i = 0; i < 8; ++i) nz |= s[i];
-    if (!nz) return;  // zero scalar (e.g. a point slot the channel does not use)
-    const uint32_t* bw = reinterpret_cast<const uint32_t*>(pr.p[q].bases + (size_t)pr.p[q].bstride * t);
-    uint32_t any = 0;
-    for (int i = 0; i < 16; ++i) any |= bw[i];
-    if (!any) return;  // identity bases contribute nothing
-    GlvHalf h[2];
-    glv_decompose(s, h[0], h[1]);
-    uint32_t nbq = p.windows * p.buckets;
+__global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const MsmProblem* __restrict__ prs, MsmPlan p, uint32_t windows_per_pass, uint32_t* __restrict__ counts,
+                                                                         const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
+    extern __shared__ uint32_t hist[];  // [windows_per_pass][buckets]
+    const uint32_t q = blockIdx.y, tile0 = blockIdx.x * MSM_TILE, tid = threadIdx.x;
+    const MsmProblem pq = prs[q];
+    const uint32_t n = pq.n;
+    if (tile0 >= n) return;  // whole workgroup: no barrier is skipped by part of a group
+    const uint32_t nbq = p.windows * p.buckets;
     const uint32_t half_range = 1u << (p.c - 1);
-    for (uint32_t hf = 0; hf < 2; ++hf) {
-        uint32_t carry = 0;
-        for (uint32_t w = 0; w < p.windows; ++w) {
-            uint32_t raw = raw_window(h[hf].mag, w, p.c) + carry;
-            bool neg_digit = raw > half_range;       // digit = raw - 2^c, carry into the next window
-            uint32_t mag = neg_digit ? (1u << p.c) - raw : raw;
-            carry = neg_digit ? 1u : 0u;
-            if (!mag) continue;
-            uint32_t b = q * nbq + w * p.buckets + mag - 1;
-            if (SCATTER) {
-                uint32_t pos = atomicAdd(&cursor[b], 1u);
-                list[offsets[b] + pos] = t | (hf ? MSM_ENTRY_HALF : 0u) | ((neg_digit != h[hf].neg) ? MSM_ENTRY_NEG : 0u);
-            } else {
-                atomicAdd(&counts[b], 1u);
+    constexpr uint32_t PER = MSM_TILE / MSM_TILE_THREADS;
+    // the lanes' terms: t = tile0 + tid + k * THREADS (coalesced); GLV halves stay in registers across the passes
+    for (uint32_t w0 = 0; w0 < p.windows; w0 += windows_per_pass) {
+        const uint32_t w1 = min(p.windows, w0 + windows_per_pass), nwords = (w1 - w0) * p.buckets;
+        for (uint32_t i = tid; i < nwords; i += MSM_TILE_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int phase = 0; phase < (SCATTER ? 2 : 1); ++phase) {
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t t = tile0 + tid + k * MSM_TILE_THREADS;
+                if (t >= n) break;
+                const uint32_t* s = t < pq.n1 ? pq.scalars + (size_t)pq.sstride * t : pq.scalars2 + (size_t)pq.sstride * (t - pq.n1);
+                uint32_t nz = 0;
+                for (int i = 0; i < 8; ++i) nz |= s[i];
+                if (!nz) continue;  // zero scalar (e.g. a point slot the channel does not use)
+                const uint32_t* bw = reinterpret_cast<const uint32_t*>(t < pq.n1 ? pq.bases + (size_t)pq.bstride * t : pq.bases2 + (size_t)pq.bstride * (t - pq.n1));
+                uint32_t any = 0;
+                for (int i = 0; i < 16; ++i) any |= bw[i];
+                if (!any) continue;  // identity bases contribute nothing
+                GlvHalf h[2];
+                glv_decompose(s, h[0], h[1]);
+                for (uint32_t hf = 0; hf < 2; ++hf) {
+                    uint32_t carry = 0;
+                    for (uint32_t w = 0; w < w1; ++w) {
+                        uint32_t raw = raw_window(h[hf].mag, w, p.c) + carry;
+                        bool neg_digit = raw > half_range;       // digit = raw - 2^c, carry into the next window
+                        uint32_t mag = neg_digit ? (1u << p.c) - raw : raw;
+                        carry = neg_digit ? 1u : 0u;
+                        if (!mag || w < w0) continue;
+                        uint32_t local = (w - w0) * p.buckets + mag - 1;
+                        if (!SCATTER || phase == 0) atomicAdd(&hist[local], 1u);
+                        else {
+                            uint32_t b = q * nbq + w * p.buckets + mag - 1;
+                            uint32_t pos = atomicAdd(&hist[local], 1u);
+                            list[offsets[b] + pos] = t | (hf ? MSM_ENTRY_HALF : 0u) | ((neg_digit != h[hf].neg) ? MSM_ENTRY_NEG : 0u);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (phase == 0) {
+                for (uint32_t i = tid; i < nwords; i += MSM_TILE_THREADS) {
+                    uint32_t v = hist[i];
+                    if (!v) continue;
+                    uint32_t b = q * nbq + w0 * p.buckets + i;
+                    if (SCATTER) hist[i] = atomicAdd(&cursor[b], v);  // this tile's first position inside bucket b
+                    else atomicAdd(&counts[b], v);
+                }
+                __syncthreads();
             }
         }
     }
@@ -188,7 +229,8 @@ __global__ void __launch_bounds__(256) msm_count_or_scatter(MsmProblems pr, MsmP
 
 // the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y)
 __device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) {
-    G1A b = q.bases[(size_t)(e & MSM_ENTRY_TERM) * q.bstride];
+    const uint32_t t = e & MSM_ENTRY_TERM;
+    G1A b = t < q.n1 ? q.bases[(size_t)t * q.bstride] : q.bases2[(size_t)(t - q.n1) * q.bstride];
     if (e & MSM_ENTRY_HALF) {
         Fq beta;  // Montgomery form of the cube root of unity 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
         beta.v[0] = 0x13e80b9cu; beta.v[1] = 0x3350c88eu; beta.v[2] = 0xdb5e56b9u; beta.v[3] = 0x7dce557cu;
@@ -219,20 +261,39 @@ __global__ void __launch_bounds__(1024) msm_scan(const uint32_t* __restrict__ co
     for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; cursor[i] = 0; }
 }
 
+// complete (slow, call-based) group law for the rare bucket in which a point meets itself or its negative
+__device__ __noinline__ void msm_bucket_slow(const MsmProblem q, const uint32_t* __restrict__ entries, uint32_t cnt, G1J* __restrict__ out) {
+    G1J acc = G1J::identity();
+    for (uint32_t i = 0; i < cnt; ++i) acc = g1_add_affine(acc, msm_entry_base(q, entries[i]));
+    *out = acc;
+}
+__device__ __noinline__ void msm_slice_slow(const G1J* __restrict__ bp, uint32_t lo, uint32_t hi, uint32_t c, G1J* __restrict__ out) {
+    G1J run = G1J::identity(), sum = G1J::identity();
+    for (uint32_t b = hi; b > lo; --b) { run = g1_add(run, bp[b - 1]); sum = g1_add(sum, run); }
+    if (lo < hi && lo > 0) {
+        G1J scaled = G1J::identity();
+        for (int i = (int)c - 1; i >= 0; --i) { scaled = g1_dbl(scaled); if ((lo >> i) & 1) scaled = g1_add(scaled, run); }
+        sum = g1_add(sum, scaled);
+    }
+    *out = sum;
+}
+
 // after the scatter `cursor` is free: it becomes the list of heavy buckets, counts[nb] their number
-__global__ void __launch_bounds__(64) msm_bucket(MsmProblems pr, uint32_t nbq, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(64) msm_bucket(const MsmProblem* __restrict__ prs, uint32_t nbq, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                  const uint32_t* __restrict__ list, uint32_t* __restrict__ heavy, G1J* __restrict__ bucket_pts, uint32_t nb, uint32_t heavy_threshold) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t cnt = counts[b], off = offsets[b];
     if (cnt > heavy_threshold) { heavy[atomicAdd(&counts[nb], 1u)] = b; return; }
-    const MsmProblem q = pr.p[b / nbq];
+    const MsmProblem q = prs[b / nbq];
     G1J acc = G1J::identity();
-    for (uint32_t i = 0; i < cnt; ++i) acc = g1_add_affine_inl(acc, msm_entry_base(q, list[off + i]));
+    bool ok = true;
+    for (uint32_t i = 0; i < cnt && ok; ++i) ok = g1_madd_fast(acc, msm_entry_base(q, list[off + i]));
+    if (!ok) { msm_bucket_slow(q, list + off, cnt, bucket_pts + b); return; }  // a base met itself or its negative
     bucket_pts[b] = acc;
 }
 
-__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_heavy(MsmProblems pr, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_heavy(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                                const uint32_t* __restrict__ list, const uint32_t* __restrict__ heavy,
                                                                G1J* __restrict__ bucket_pts, uint32_t nb) {
     __shared__ G1J red[MSM_HEAVY_THREADS];
@@ -242,7 +303,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_heavy(MsmProblems pr, u
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         uint32_t b = heavy[h];
         uint32_t cnt = counts[b], off = offsets[b];
-        const MsmProblem q = pr.p[b / nbq];
+        const MsmProblem q = prs[b / nbq];
         G1J acc = G1J::identity();
         for (uint32_t i = t; i < cnt; i += MSM_HEAVY_THREADS) acc = g1_add_affine(acc, msm_entry_base(q, list[off + i]));
         red[t] = acc;
@@ -263,20 +324,22 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restr
     uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
     G1J run = G1J::identity(), sum = G1J::identity();
     const G1J* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
-    for (uint32_t b = hi; b > lo; --b) {
-        run = g1_add_inl(run, bp[b - 1]);
-        sum = g1_add_inl(sum, run);
+    bool ok = true;
+    for (uint32_t b = hi; b > lo && ok; --b) {
+        ok = g1_add_fast(run, bp[b - 1]);
+        if (ok) ok = g1_add_fast(sum, run);
     }
-    // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1)
-    if (lo < hi && lo > 0) {
+    // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
+    if (ok && lo < hi && lo > 0) {
         G1J scaled = G1J::identity();
-        for (int i = (int)p.c - 1; i >= 0; --i) {
-            scaled = g1_dbl(scaled);
-            if ((lo >> i) & 1) scaled = g1_add(scaled, run);
+        for (int i = (int)p.c - 1; i >= 0 && ok; --i) {
+            scaled = g1_dbl_inl(scaled);
+            if ((lo >> i) & 1) ok = g1_add_fast(scaled, run);
         }
-        sum = g1_add(sum, scaled);
+        if (ok) ok = g1_add_fast(sum, scaled);
     }
-    red[t] = sum;
+    if (ok) red[t] = sum;
+    else msm_slice_slow(bp, lo, hi, p.c, &red[t]);  // degenerate meeting of equal / opposite points: complete formulas
     __syncthreads();
     for (uint32_t d = MSM_WIN_THREADS / 2; d > 0; d >>= 1) {
         if (t < d) red[t] = g1_add(red[t], red[t + d]);
@@ -285,53 +348,68 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restr
     if (t == 0) window_sums[(size_t)q * p.windows + w] = red[0];
 }
 
-__global__ void __launch_bounds__(64) msm_final(const G1J* __restrict__ window_sums, MsmProblems pr, MsmPlan p) {
+__global__ void __launch_bounds__(64) msm_final(const G1J* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= pr.count) return;
+    if (q >= count) return;
     G1J acc = G1J::identity();
-    if (pr.p[q].n) {
+    if (prs[q].n) {
         for (int w = (int)p.windows - 1; w >= 0; --w) {
             for (uint32_t i = 0; i < p.c; ++i) acc = g1_dbl_inl(acc);
             acc = g1_add(acc, window_sums[(size_t)q * p.windows + w]);
         }
     }
-    *pr.p[q].out = acc;
+    *prs[q].out = acc;
+}
+
+// descriptors travel as kernel arguments, a chunk at a time: no host staging buffer whose lifetime the caller would have to manage
+__global__ void msm_set_problems(MsmProblemChunk ch, uint32_t count, MsmProblem* __restrict__ dst) {
+    uint32_t i = threadIdx.x;
+    if (i < count) dst[i] = ch.p[i];
 }
 
 int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
-    if (pr.count == 0) return 0;
-    if (pr.count > MSM_MAX_PROBLEMS || pr.count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
+    const uint32_t count = (uint32_t)pr.p.size();
+    if (count == 0) return 0;
+    if (count > MSM_MAX_PROBLEMS || count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
     uint32_t nmax = 0; size_t total = 0;
-    for (uint32_t q = 0; q < pr.count; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; }
+    for (uint32_t q = 0; q < count; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; }
+    for (uint32_t q0 = 0; q0 < count; q0 += MSM_PROBLEM_CHUNK) {
+        MsmProblemChunk ch;
+        uint32_t k = std::min<uint32_t>(MSM_PROBLEM_CHUNK, count - q0);
+        for (uint32_t i = 0; i < k; ++i) ch.p[i] = pr.p[q0 + i];
+        hipLaunchKernelGGL(msm_set_problems, dim3(1), dim3(64), 0, s, ch, k, ws.problems + q0);
+    }
     if (nmax == 0) {
-        hipLaunchKernelGGL(msm_final, dim3(1), dim3(64), 0, s, ws.window_sums, pr, MsmPlan{0, 2, 0, 3});
+        hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, MsmPlan{0, 2, 0, 3});
         H2V_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (nmax > MSM_ENTRY_TERM) { set_last_error("msm_enqueue_multi: more than 2^30 terms in one problem"); return H2V_ERR_BAD_ARGUMENT; }
     if (total > ws.cap_terms) { set_last_error("msm_enqueue_multi: terms exceed workspace capacity"); return H2V_ERR_BAD_ARGUMENT; }
     MsmPlan p = msm_plan(nmax);
-    uint32_t nbq = p.windows * p.buckets, nb = nbq * pr.count;
+    uint32_t nbq = p.windows * p.buckets, nb = nbq * count;
     if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 1) * 4, s));
-    dim3 gt((nmax + 255) / 256, pr.count);
-    hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(256), 0, s, pr, p, ws.counts, ws.offsets, ws.cursor, ws.list);
+    dim3 gt((nmax + MSM_TILE - 1) / MSM_TILE, count);
+    const uint32_t wpp = std::max<uint32_t>(1u, std::min<uint32_t>(p.windows, MSM_LDS_WORDS / p.buckets));
+    const size_t lds = (size_t)wpp * p.buckets * 4;
+    hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
     hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, s, ws.counts, ws.offsets, ws.cursor, nb);
-    hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(256), 0, s, pr, p, ws.counts, ws.offsets, ws.cursor, ws.list);
+    hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
     // with random scalars a bucket holds about 2n / buckets entries; outliers go to the workgroup path: skewed inputs, and the
     // top window, whose digits span fewer bits (128 is not a multiple of c) so that its buckets collect several times the average
     uint32_t heavy_threshold = std::max<uint32_t>(MSM_HEAVY_MIN, 2u * (uint32_t)((2ull * nmax + p.buckets - 1) / p.buckets));
-    hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb, heavy_threshold);
-    hipLaunchKernelGGL(msm_heavy, dim3(512), dim3(MSM_HEAVY_THREADS), 0, s, pr, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
-    hipLaunchKernelGGL(msm_window, dim3(p.windows, pr.count), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
-    hipLaunchKernelGGL(msm_final, dim3((pr.count + 63) / 64), dim3(64), 0, s, ws.window_sums, pr, p);
+    hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb, heavy_threshold);
+    hipLaunchKernelGGL(msm_heavy, dim3(512), dim3(MSM_HEAVY_THREADS), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
+    hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
+    hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, const G1A* d_bases, uint32_t n, G1J* d_out) {
-    MsmProblems pr; pr.count = 1;
-    pr.p[0] = MsmProblem{d_scalars, d_bases, d_out, 8, 1, n};
+    MsmProblems pr;
+    pr.p.push_back(MsmProblem(d_scalars, d_bases, d_out, 8, 1, n));
     return msm_enqueue_multi(s, ws, pr);
 }
 

@@ -40,12 +40,12 @@ __global__ void k_point_to_bytes(const G1J* __restrict__ in, uint8_t* __restrict
     for (int j = 0; j < 64; ++j) out[64 * (size_t)i + j] = tmp[j];
 }
 
-__global__ void k_fold_pairs(const G1J* __restrict__ parts, uint32_t n_parts, G1J* __restrict__ acc2) {
-    uint32_t ch = threadIdx.x;  // lane 0: left channel, lane 1: right channel
-    if (blockIdx.x != 0 || ch >= 2) return;
-    G1J acc = G1J::identity();
-    for (uint32_t i = 0; i < n_parts; ++i) acc = g1_add(acc, parts[2 * i + ch]);
-    acc2[ch] = acc;
+__global__ void k_fold_pairs(const G1J* __restrict__ parts, uint32_t n_parts, G1J* __restrict__ acc, uint32_t width) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;  // even: a left channel, odd: a right channel
+    if (k >= width) return;
+    G1J sum = G1J::identity();
+    for (uint32_t i = 0; i < n_parts; ++i) sum = g1_add(sum, parts[(size_t)i * width + k]);
+    acc[k] = sum;
 }
 
 __global__ void k_affine_to_jacobian(const G1A* __restrict__ in, G1J* __restrict__ out, uint32_t n) {
@@ -77,8 +77,8 @@ int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, 
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc2) {
-    hipLaunchKernelGGL(k_fold_pairs, dim3(1), dim3(64), 0, s, d_parts, n_parts, d_acc2);
+int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc, uint32_t width) {
+    hipLaunchKernelGGL(k_fold_pairs, dim3((width + 63) / 64), dim3(64), 0, s, d_parts, n_parts, d_acc, width);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -236,9 +236,11 @@ __global__ void __launch_bounds__(64) k_transcript_keccak(const unsigned long lo
 }
 
 // mult[p] = prod_{j > first+p} r_j over the tail of draws; tail[0] is the draw of this shard's proof 0.
+// One workgroup per group of a grouped batch (blockIdx.x = group; n_tail and n are per group).
 __global__ void __launch_bounds__(1024) k_multipliers(const uint8_t* __restrict__ tail, uint32_t n_tail, uint32_t n, Fr* __restrict__ mult) {
     __shared__ Fr part[1024];
     uint32_t t = threadIdx.x;
+    tail += (size_t)blockIdx.x * n_tail * 32; mult += (size_t)blockIdx.x * n;
     uint32_t chunk = (n_tail + 1023) / 1024;
     uint32_t lo = min(n_tail, t * chunk), hi = min(n_tail, lo + chunk);
     Fr prod = Fr::one();
@@ -346,12 +348,12 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
     }
 }
 
-// msm_scal[(n*np + j)] = canonical( sum_p shared[j][p] )
-__global__ void __launch_bounds__(256) k_fold_shared(const Fr* __restrict__ shared, uint32_t n, uint32_t np, uint32_t* __restrict__ msm_scal) {
+// msm_scal[n*np + g*n_shared + j] = canonical( sum over the proofs p of group g of shared[j][p] )
+__global__ void __launch_bounds__(256) k_fold_shared(const Fr* __restrict__ shared, uint32_t n, uint32_t np, uint32_t gs, uint32_t* __restrict__ msm_scal) {
     __shared__ Fr red[256];
-    uint32_t j = blockIdx.x, t = threadIdx.x;
+    uint32_t j = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
     Fr acc = Fr::zero();
-    for (uint32_t p = t; p < n; p += 256) acc = acc + shared[(size_t)j * n + p];
+    for (uint32_t p = g * gs + t; p < (g + 1) * gs; p += 256) acc = acc + shared[(size_t)j * n + p];
     red[t] = acc;
     __syncthreads();
     for (uint32_t d = 128; d > 0; d >>= 1) {
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(256) k_fold_shared(const Fr* __restrict__ shar
     }
     if (t == 0) {
         uint32_t raw[8]; red[0].to_raw(raw);
-        uint32_t* dst = msm_scal + ((size_t)n * np + j) * 8;
+        uint32_t* dst = msm_scal + ((size_t)n * np + (size_t)g * gridDim.x + j) * 8;
         for (int i = 0; i < 8; ++i) dst[i] = raw[i];
     }
 }
@@ -435,8 +437,8 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, Fr* d_mult) {
-    hipLaunchKernelGGL(k_multipliers, dim3(1), dim3(1024), 0, s, d_tail, n_tail, n, d_mult);
+int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult) {
+    hipLaunchKernelGGL(k_multipliers, dim3(groups), dim3(1024), 0, s, d_tail, n_tail / groups, n / groups, d_mult);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -446,9 +448,9 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a) {
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t* d_msm_scal) {
+int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal) {
     if (!n_shared) return 0;
-    hipLaunchKernelGGL(k_fold_shared, dim3(n_shared), dim3(256), 0, s, d_shared, n, np, d_msm_scal);
+    hipLaunchKernelGGL(k_fold_shared, dim3(n_shared, groups), dim3(256), 0, s, d_shared, n, np, n / groups, d_msm_scal);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -23,11 +23,12 @@ ACC_BYTES = 192  # 2 x Jacobian G1 (3 x 32 B Montgomery limbs)
 
 
 def gather_accumulators(local_acc, world_size, group=None):
-    """all_gather of the per-rank accumulator bytes (torch uint8 tensor of ACC_BYTES) -> tensor [world_size * ACC_BYTES].
+    """all_gather of the per-rank accumulator bytes (torch uint8 tensor of groups * ACC_BYTES, as Batch.export_accumulators
+    writes them) -> tensor [world_size * groups * ACC_BYTES], the layout Batch.fold_check_enqueue folds group by group.
     Works with the nccl (= RCCL) backend on GPU tensors and with gloo on CPU tensors (tests)."""
     import torch
     import torch.distributed as dist
-    out = torch.empty(world_size * ACC_BYTES, dtype=torch.uint8, device=local_acc.device)
+    out = torch.empty(world_size * local_acc.numel(), dtype=torch.uint8, device=local_acc.device)
     if world_size == 1:
         out.copy_(local_acc)
         return out

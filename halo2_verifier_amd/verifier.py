@@ -264,14 +264,23 @@ class Batch:
 
     STAGES = ("decompress", "transcript", "fr_program", "fold", "msm", "pairing")
 
-    def __init__(self, ctx: Context, max_proofs: int, max_instance_values: int = 0, stream=None):
+    def __init__(self, ctx: Context, max_proofs: int, max_instance_values: int = 0, stream=None, groups: int = 1):
         self.ctx, self._lib = ctx, ctx._lib
         self._h = ctypes.c_void_p()
         check(self._lib.h2v_batch_create(ctx._h, max_proofs, max_instance_values, ctypes.byref(self._h)))
         self.max_proofs = max_proofs
         self.n = 0
+        self.groups = 1
         if stream is not None:
             self.set_stream(stream)
+        if groups != 1:
+            self.set_groups(groups)
+
+    def set_groups(self, groups: int):
+        """`groups` independent AccumulatorStrategy batches per upload/launch (h2v_batch_set_groups): group g owns proofs
+        [g*n/groups, (g+1)*n/groups) and the same slice of the draws; each has its own accumulators and pairing."""
+        check(self._lib.h2v_batch_set_groups(self._h, groups))
+        self.groups = groups
 
     def close(self):
         if self._h:
@@ -316,6 +325,16 @@ class Batch:
         left, right = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
         check(self._lib.h2v_batch_finish(self._h, st, ctypes.byref(ok), left, right))
         return bool(ok.value), list(st)[:self.n], left.raw, right.raw
+
+    def finish_groups(self):
+        """-> (group_ok[groups], statuses, left_xy[groups], right_xy[groups])"""
+        g = self.groups
+        st = (ctypes.c_int * max(self.n, 1))()
+        ok = (ctypes.c_int * g)()
+        left, right = ctypes.create_string_buffer(64 * g), ctypes.create_string_buffer(64 * g)
+        check(self._lib.h2v_batch_finish_groups(self._h, st, ok, left, right, g))
+        return ([bool(v) for v in ok], list(st)[:self.n], [left.raw[64 * i:64 * i + 64] for i in range(g)],
+                [right.raw[64 * i:64 * i + 64] for i in range(g)])
 
     def set_profiling(self, on=True):
         check(self._lib.h2v_batch_set_profiling(self._h, 1 if on else 0))

@@ -147,7 +147,15 @@ int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t 
 int h2v_batch_launch(h2v_batch* b, int with_pairing);
 /* Wait for the stream and fetch results (any pointer may be NULL). */
 int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
-/* Device address of this batch's two accumulator points after launch: 2 x 96 bytes, Jacobian
+/* Grouped batches: one upload / launch carries `groups` INDEPENDENT AccumulatorStrategy batches (kzg/strategy.rs:99-141 each):
+ * group g owns proofs [g*n/groups, (g+1)*n/groups) and the draws rand32_tail[g*n_tail/groups, (g+1)*n_tail/groups), has its own
+ * pair of accumulators and its own pairing check — exactly what `groups` separate h2v_batch objects would compute, but with
+ * every kernel launched once for all of them (the pairing and the tail of the MSM are latency-bound single-wave kernels, so G
+ * of them side by side cost the time of one).  n and n_tail of later uploads must be multiples of `groups`.  Call before upload. */
+int h2v_batch_set_groups(h2v_batch* b, size_t groups);
+/* As h2v_batch_finish for a grouped batch: group_ok[n_groups], out_left_xy / out_right_xy = n_groups x 64 bytes. */
+int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left_xy, uint8_t* out_right_xy, size_t n_groups);
+/* Device address of this batch's accumulator points after launch: per group [left, right], 2 x 96 bytes each, Jacobian
  * (X, Y, Z) in the library's Montgomery limb layout — opaque bytes to be moved by a collective. */
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes);
 /* The HIP stream (hipStream_t) the batch runs on, for event timing and stream-ordered interop. */
@@ -156,10 +164,11 @@ void* h2v_batch_stream(h2v_batch* b);
  * so that collectives issued by the caller on that stream are ordered with the batch's kernels without
  * host synchronisation.  The caller keeps the stream alive while the batch uses it. */
 int h2v_batch_set_stream(h2v_batch* b, void* hip_stream);
-/* Stream-ordered copy of the two accumulator points (2 x 96 bytes) into caller device memory. */
+/* Stream-ordered copy of the accumulator points (groups x 2 x 96 bytes) into caller device memory. */
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst);
 /* Stream-ordered version of h2v_fold_check on the batch's stream: fold n_parts gathered accumulator
- * pairs and enqueue the single pairing; the result is fetched by h2v_batch_finish (batch_ok, left, right). */
+ * sets (each laid out as h2v_batch_export_accumulators writes it: [group][left, right]) group by group and enqueue one
+ * pairing per group; the result is fetched by h2v_batch_finish / h2v_batch_finish_groups (ok, left, right). */
 int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts);
 /* Fold n_parts accumulator pairs (as produced by h2v_batch_accumulators, contiguous in device
  * memory) with G1 additions and run the single pairing check.
