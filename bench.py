@@ -179,7 +179,7 @@ def main():
             with torch.cuda.stream(streams[i]):
                 b.launch(with_pairing=False)
                 b.export_accumulators(acc_local[i].data_ptr())
-                gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 192 B per rank
+                gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 216 B per rank
                 b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
         in_flight[i] = True
 

@@ -1,7 +1,17 @@
 // BN254 prime-field arithmetic for gfx950 (and the host side of the same library).
 //
-// 8 x 32-bit limbs, Montgomery form (R = 2^256), fully reduced after every operation.
-// CDNA4 has no 64x64->128 VALU multiply; the inner step is v_mad_u64_u32 (32x32 + 64).
+// Representation: 9 limbs of 29 bits (value = sum v[i] * 2^(29 i)), Montgomery form with R = 2^261, kept in [0, 2p)
+// ("lazily" reduced: the canonical representative is produced only where bytes or comparisons need it).
+//
+// Why 29-bit limbs: CDNA4 has no 64x64->128 multiply and no multiply-add with carry-in; the widest step is
+// v_mad_u64_u32 (32x32 + 64 -> 64).  With 32-bit limbs every such step needs its addend zero-extended and its carry
+// split off again — the compiled 8 x 32 CIOS product is 128 multiply-adds buried in ~400 moves and 64-bit adds.  With
+// 29-bit limbs a whole column of the product, a_i*b_j and m_i*p_j alike (18 terms < 2^58), fits a 64-bit accumulator,
+// so the product is 162 back-to-back v_mad_u64_u32 into one register pair plus a shift and a mask per column: ~235
+// instructions instead of ~530, 2.2x faster on a lone wave and 2x at full occupancy (tools/limb29_microbench.hip).
+// R = 2^261 > 32p also removes the final conditional subtraction: inputs < 2p give outputs < 1.04p.
+// Additions cost a little more (no hardware carry chain across 29-bit limbs), but the kernels are product-bound.
+//
 // Both Fq (curve coordinates) and Fr (scalars, challenges, evaluations) use this template.
 //
 // This is the product's own arithmetic; it shares no code with oracle/ (which uses 4 x 64-bit
@@ -20,63 +30,100 @@
 // Small helpers are plain inline; the multi-hundred-instruction bodies (Montgomery product,
 // exponentiation, group law, tower products) are real function calls on the device: inlining
 // them everywhere makes kernels like the pairing explode in code size and compile time, while a
-// call costs a few dozen cycles against a ~400-instruction body.
+// call costs a few dozen cycles against a ~250-instruction body.
 #define H2V_HD __host__ __device__ inline
 #define H2V_FN __host__ __device__ inline __attribute__((noinline))
 
 namespace h2v {
 
+#define H2V_LIMBS 9
+#define H2V_LIMB_BITS 29
+#define H2V_LIMB_MASK 0x1fffffffu
+
+// P: the modulus as 8 x 32-bit words (byte-level canonicity checks, exponents); everything else in 29-bit limbs:
+// P29 = p, ONE = R mod p, R2 = R^2 mod p, R3 = R^3 mod p, M256 = 2^256 * R mod p (the Montgomery form of 2^256),
+// K266 = 2^266 mod p (turns a 2^256-Montgomery residue, halo2curves' RawBytes limbs, into this representation).
 struct FqParams {
-    static constexpr uint32_t INV = 0xe4866389u;  // -p^{-1} mod 2^32
+    static constexpr uint32_t INV29 = 0x04866389u;  // -p^{-1} mod 2^29
     H2V_HD static constexpr uint32_t P(int i) {
         constexpr uint32_t p[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
         return p[i];
     }
-    H2V_HD static constexpr uint32_t ONE(int i) {  // R mod p
-        constexpr uint32_t v[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    H2V_HD static constexpr uint32_t P29(int i) {
+        constexpr uint32_t v[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
         return v[i];
     }
-    H2V_HD static constexpr uint32_t R2(int i) {  // R^2 mod p
-        constexpr uint32_t v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    H2V_HD static constexpr uint32_t ONE(int i) {
+        constexpr uint32_t v[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
         return v[i];
     }
-    H2V_HD static constexpr uint32_t R3(int i) {  // R^3 mod p
-        constexpr uint32_t v[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u, 0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};
+    H2V_HD static constexpr uint32_t R2(int i) {
+        constexpr uint32_t v[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u, 0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};
+        return v[i];
+    }
+    H2V_HD static constexpr uint32_t R3(int i) {
+        constexpr uint32_t v[9] = {0x0e2312b2u, 0x16c05ca2u, 0x0bc84389u, 0x1cdf310bu, 0x11adafddu, 0x032e568eu, 0x1d6ae48cu, 0x10d4cd1fu, 0x0026c2d2u};
+        return v[i];
+    }
+    H2V_HD static constexpr uint32_t M256(int i) {
+        constexpr uint32_t v[9] = {0x0f6b5c04u, 0x08ead878u, 0x1645525du, 0x1aefe9cdu, 0x09d605edu, 0x0483a115u, 0x0d08508bu, 0x0dba4804u, 0x001982b4u};
+        return v[i];
+    }
+    H2V_HD static constexpr uint32_t K266(int i) {
+        constexpr uint32_t v[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
         return v[i];
     }
 };
 struct FrParams {
-    static constexpr uint32_t INV = 0xefffffffu;
+    static constexpr uint32_t INV29 = 0x0fffffffu;
     H2V_HD static constexpr uint32_t P(int i) {
         constexpr uint32_t p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
         return p[i];
     }
+    H2V_HD static constexpr uint32_t P29(int i) {
+        constexpr uint32_t v[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+        return v[i];
+    }
     H2V_HD static constexpr uint32_t ONE(int i) {
-        constexpr uint32_t v[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        constexpr uint32_t v[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
         return v[i];
     }
     H2V_HD static constexpr uint32_t R2(int i) {
-        constexpr uint32_t v[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        constexpr uint32_t v[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
         return v[i];
     }
     H2V_HD static constexpr uint32_t R3(int i) {
-        constexpr uint32_t v[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
+        constexpr uint32_t v[9] = {0x001fddb2u, 0x17d30b63u, 0x1a2600eeu, 0x09507c47u, 0x1496b29bu, 0x0b00a268u, 0x15b645ebu, 0x1f9fcb3du, 0x001baa96u};
+        return v[i];
+    }
+    H2V_HD static constexpr uint32_t M256(int i) {
+        constexpr uint32_t v[9] = {0x142db4dfu, 0x19d6990eu, 0x1472f48cu, 0x06dbe7e3u, 0x0b84d579u, 0x10f9faf7u, 0x121f4380u, 0x17a112deu, 0x001275c7u};
+        return v[i];
+    }
+    H2V_HD static constexpr uint32_t K266(int i) {
+        constexpr uint32_t v[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
         return v[i];
     }
 };
 
 template <class PR> struct Fp {
-    uint32_t v[8];
+    uint32_t v[H2V_LIMBS];  // 29-bit limbs of a representative in [0, 2p) of (value * R) mod p
 
-    H2V_HD static Fp zero() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = 0; return r; }
-    H2V_HD static Fp one() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::ONE(i); return r; }
-    H2V_HD static Fp r2() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = PR::R2(i); return r; }
+    H2V_HD static Fp zero() { Fp r; for (int i = 0; i < 9; ++i) r.v[i] = 0; return r; }
+    H2V_HD static Fp one() { Fp r; for (int i = 0; i < 9; ++i) r.v[i] = PR::ONE(i); return r; }
+    H2V_HD static Fp r2() { Fp r; for (int i = 0; i < 9; ++i) r.v[i] = PR::R2(i); return r; }
 
-    H2V_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= v[i]; return o == 0; }
-    H2V_HD bool operator==(const Fp& b) const { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= v[i] ^ b.v[i]; return o == 0; }
+    // [0, 2p): zero is the limb string 0 or the limb string p
+    H2V_HD bool is_zero() const {
+        uint32_t o = 0, q = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { o |= v[i]; q |= v[i] ^ PR::P29(i); }
+        return o == 0 || q == 0;
+    }
+    H2V_HD bool operator==(const Fp& b) const { return (*this - b).is_zero(); }
     H2V_HD bool operator!=(const Fp& b) const { return !(*this == b); }
 
-    // raw (non-Montgomery) limb comparison a >= p
+    // raw (non-Montgomery) 8 x 32-bit word comparison a >= p
     H2V_HD static bool geq_p(const uint32_t a[8]) {
         for (int i = 7; i >= 0; --i) {
             uint32_t p = PR::P(i);
@@ -85,92 +132,156 @@ template <class PR> struct Fp {
         }
         return true;
     }
-    // carry chains written with __builtin_addc / __builtin_subc so that they lower to v_add_co / v_addc_co (one
-    // instruction per limb) instead of 64-bit adds and shifts: an Fq addition is ~24 instructions, not ~130
-    H2V_HD static uint32_t sub_p(uint32_t r[8], const uint32_t a[8]) {
-        unsigned borrow = 0;
+    // 256-bit integer as 8 words <-> 9 limbs (plain repacking, no arithmetic)
+    H2V_HD static void pack29(uint32_t out[9], const uint32_t raw[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = __builtin_subc(a[i], PR::P(i), borrow, &borrow);
-        return borrow;
+        for (int i = 0; i < 9; ++i) {
+            const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+            uint32_t x = raw[w] >> sh;
+            if (sh > 3 && w + 1 < 8) x |= raw[w + 1] << (32 - sh);
+            out[i] = x & H2V_LIMB_MASK;
+        }
+    }
+    H2V_HD static void unpack29(uint32_t raw[8], const uint32_t in[9]) {  // in < 2^256
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int bit = 32 * w, i = bit / 29, sh = bit % 29;
+            uint32_t x = in[i] >> sh;                       // 29 - sh bits
+            x |= in[i + 1] << (29 - sh);                    // i + 1 <= 8 always: 32*7 / 29 = 7
+            if (29 - sh + 29 < 32 && i + 2 < 9) x |= in[i + 2] << (58 - sh);
+            raw[w] = x;
+        }
+    }
+    // the canonical representative's limbs
+    H2V_HD void canonical(uint32_t out[9]) const {
+        int32_t u[9]; int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int32_t w = (int32_t)v[i] - (int32_t)PR::P29(i) + c;
+            if (i < 8) { u[i] = w & (int32_t)H2V_LIMB_MASK; c = w >> 29; } else u[i] = w;
+        }
+        const bool neg = u[8] < 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] = neg ? v[i] : (uint32_t)u[i];
     }
 
+    // a + b and a - b for representatives < 2p, result < 2p: limb-wise with signed carries, one conditional +-2p
     H2V_HD Fp operator+(const Fp& b) const {
-        uint32_t t[8]; unsigned carry = 0;
+        uint32_t t[9]; int32_t u[9];
+        uint32_t ct = 0; int32_t cu = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = __builtin_addc(v[i], b.v[i], carry, &carry);
-        // p < 2^254: a + b < 2^255, no carry out of limb 7
-        uint32_t u[8]; uint32_t borrow = sub_p(u, t);
+        for (int i = 0; i < 9; ++i) {
+            const uint32_t s0 = v[i] + b.v[i];
+            const uint32_t s = s0 + ct;
+            const int32_t w = (int32_t)s0 - (int32_t)(2u * PR::P29(i)) + cu;
+            if (i < 8) { t[i] = s & H2V_LIMB_MASK; ct = s >> 29; u[i] = w & (int32_t)H2V_LIMB_MASK; cu = w >> 29; }
+            else { t[i] = s; u[i] = w; }
+        }
+        const bool neg = u[8] < 0;  // a + b < 2p
         Fp r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = borrow ? t[i] : u[i];
+        for (int i = 0; i < 9; ++i) r.v[i] = neg ? t[i] : (uint32_t)u[i];
         return r;
     }
     H2V_HD Fp operator-(const Fp& b) const {
-        uint32_t t[8]; unsigned borrow = 0;
+        int32_t t[9], u[9];
+        int32_t ct = 0, cu = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = __builtin_subc(v[i], b.v[i], borrow, &borrow);
-        unsigned carry = 0; Fp r;
-        const uint32_t mask = borrow ? 0xffffffffu : 0u;
+        for (int i = 0; i < 9; ++i) {
+            const int32_t d = (int32_t)v[i] - (int32_t)b.v[i];
+            const int32_t s = d + ct;
+            const int32_t w = d + (int32_t)(2u * PR::P29(i)) + cu;
+            if (i < 8) { t[i] = s & (int32_t)H2V_LIMB_MASK; ct = s >> 29; u[i] = w & (int32_t)H2V_LIMB_MASK; cu = w >> 29; }
+            else { t[i] = s; u[i] = w; }
+        }
+        const bool neg = t[8] < 0;  // a < b: take a - b + 2p
+        Fp r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = __builtin_addc(t[i], PR::P(i) & mask, carry, &carry);
+        for (int i = 0; i < 9; ++i) r.v[i] = (uint32_t)(neg ? u[i] : t[i]);
         return r;
     }
     H2V_HD Fp neg() const { return zero() - *this; }
     H2V_HD Fp dbl() const { return *this + *this; }
 
-    // Montgomery product a*b/R mod p (CIOS).  Inputs < p  =>  output < p.
-    // Also correct for a < 2^256 (unreduced) with b < p: the running value stays < 2^256 + p.
+    // Montgomery product a*b/R mod p by product scanning: column k collects a_i*b_(k-i) and m_i*p_(k-i) in one 64-bit
+    // accumulator (<= 18 terms < 2^58 each, plus a carry < 2^35), m_k is chosen to clear the column's low 29 bits.
+    // Any limb-normalised inputs are safe against overflow; representatives < 2p give a result < 1.04p.
     __host__ __device__ __forceinline__ static Fp mul_inl(const Fp& a, const Fp& b) {
-        uint32_t t[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) t[i] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint64_t carry = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + carry;
-                t[j] = (uint32_t)s; carry = s >> 32;
-            }
-            uint64_t top = (uint64_t)t[8] + carry;
-            uint32_t m = t[0] * PR::INV;
-            carry = ((uint64_t)m * PR::P(0) + t[0]) >> 32;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) {
-                uint64_t s = (uint64_t)m * PR::P(j) + t[j] + carry;
-                t[j - 1] = (uint32_t)s; carry = s >> 32;
-            }
-            top += carry;
-            t[7] = (uint32_t)top; t[8] = (uint32_t)(top >> 32);
-        }
-        uint32_t u[8]; uint32_t borrow = sub_p(u, t);
-        bool take_sub = t[8] != 0 || !borrow;
+        uint64_t acc = 0;
+        uint32_t m[9];
         Fp r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.v[i] = take_sub ? u[i] : t[i];
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * PR::P29(k - i);
+            m[k] = ((uint32_t)acc * PR::INV29) & H2V_LIMB_MASK;
+            acc += (uint64_t)m[k] * PR::P29(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * PR::P29(k - i);
+            r.v[k - 9] = (uint32_t)acc & H2V_LIMB_MASK;
+            acc >>= 29;
+        }
+        r.v[8] = (uint32_t)acc;
+        return r;
+    }
+    // a^2/R mod p: the 36 off-diagonal products are taken once against doubled limbs (45 + 81 multiply-adds instead of 162)
+    __host__ __device__ __forceinline__ Fp sqr_inl() const {
+        uint64_t acc = 0;
+        uint32_t m[9], d[9];
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] = v[i] << 1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)d[i] * v[k - i];
+            if (k % 2 == 0) acc += (uint64_t)v[k / 2] * v[k / 2];
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * PR::P29(k - i);
+            m[k] = ((uint32_t)acc * PR::INV29) & H2V_LIMB_MASK;
+            acc += (uint64_t)m[k] * PR::P29(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)d[i] * v[k - i];
+            if (k % 2 == 0) acc += (uint64_t)v[k / 2] * v[k / 2];
+#pragma unroll
+            for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * PR::P29(k - i);
+            r.v[k - 9] = (uint32_t)acc & H2V_LIMB_MASK;
+            acc >>= 29;
+        }
+        r.v[8] = (uint32_t)acc;
         return r;
     }
     // The same product as a real function call (operands and result by value, i.e. in VGPRs).  Mid-level routines
     // (Fq2 products, the G1 group law) inline mul_inl so that their independent products can be interleaved by the
-    // scheduler — a lone wave is latency-bound on the carry chains of a single product — while everything else
-    // calls this one copy to keep code size and compile time bounded.
+    // scheduler, while everything else calls this one copy to keep code size and compile time bounded.
     H2V_FN static Fp mul(Fp a, Fp b) { return mul_inl(a, b); }
-    __host__ __device__ __forceinline__ Fp sqr_inl() const { return mul_inl(*this, *this); }
+    H2V_FN static Fp sqr_fn(Fp a) { return a.sqr_inl(); }
     H2V_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
-    H2V_HD Fp sqr() const { return mul(*this, *this); }
+    H2V_HD Fp sqr() const { return sqr_fn(*this); }
 
-    // canonical integer (as limbs) -> Montgomery.  Requires raw < p.
-    H2V_HD static Fp from_raw(const uint32_t raw[8]) { Fp t; for (int i = 0; i < 8; ++i) t.v[i] = raw[i]; return mul(t, r2()); }
-    // any 256-bit integer -> Montgomery (reduces first; 2^256 < 6p)
-    H2V_HD static Fp from_raw_unreduced(const uint32_t raw[8]) {
-        uint32_t t[8]; for (int i = 0; i < 8; ++i) t[i] = raw[i];
-        for (int k = 0; k < 5; ++k) { uint32_t u[8]; uint32_t borrow = sub_p(u, t); if (!borrow) for (int i = 0; i < 8; ++i) t[i] = u[i]; }
-        return from_raw(t);
-    }
+    // integer < 2^256 (as words) -> Montgomery form of its residue
+    H2V_HD static Fp from_raw(const uint32_t raw[8]) { Fp t; pack29(t.v, raw); return mul(t, r2()); }
+    H2V_HD static Fp from_raw_unreduced(const uint32_t raw[8]) { return from_raw(raw); }  // 2^256 < 8p: a valid product operand as is
+    // residue in 2^256-Montgomery form (words, < p) -> this representation: m * 2^266 / 2^261 = m * 2^5 = a * 2^261
+    H2V_HD static Fp from_mont256(const uint32_t m[8]) { Fp t, k; pack29(t.v, m); for (int i = 0; i < 9; ++i) k.v[i] = PR::K266(i); return mul(t, k); }
+    // canonical integer of the value, as words
     H2V_HD void to_raw(uint32_t out[8]) const {
         Fp o = zero(); o.v[0] = 1;
         Fp r = mul(*this, o);
-        for (int i = 0; i < 8; ++i) out[i] = r.v[i];
+        uint32_t c[9]; r.canonical(c);
+        unpack29(out, c);
     }
     H2V_HD static Fp from_u32(uint32_t x) { uint32_t raw[8] = {x, 0, 0, 0, 0, 0, 0, 0}; return from_raw(raw); }
 
@@ -188,8 +299,9 @@ template <class PR> struct Fp {
     }
     // 512-bit little-endian integer mod p (ff::FromUniformBytes<64>); w[0..15] = LE words
     H2V_HD static Fp from_uniform_words(const uint32_t w[16]) {
-        Fp lo = from_raw_unreduced(w), hi = from_raw_unreduced(w + 8);
-        return lo + hi * r2();  // the element with Montgomery limbs R^2 is the value R = 2^256
+        Fp lo = from_raw(w), hi = from_raw(w + 8), m256;
+        for (int i = 0; i < 9; ++i) m256.v[i] = PR::M256(i);
+        return lo + hi * m256;
     }
 
     // x^e for a 32-bit exponent, MSB first.  The exponent is wave-uniform wherever the kernels use
@@ -223,15 +335,16 @@ template <class PR> struct Fp {
         e[0] -= 2;  // p is odd and its low limb is >= 2 for both fields
         return pow_limbs(e);
     }
-    // Inverse by the binary extended Euclidean algorithm on the raw limbs: <= 2*254 shift/subtract steps of ~70
-    // instructions instead of 320 Montgomery products of ~600 — about 5x fewer instructions on the lanes' critical
-    // path (the Fr program's one inversion per proof, the affine conversions, the Fq12 inversion of the pairing).
-    // Works on the Montgomery limbs m = aR as a plain integer: m^-1 = a^-1 R^-1, and one product with R^3 gives a^-1 R.
-    // inv(0) = 0.  The loop is bounded, so every lane leaves it.
+    // Inverse by the binary extended Euclidean algorithm on 32-bit words: <= 2*254 shift/subtract steps of ~70
+    // instructions instead of ~320 Montgomery products — fewer instructions on a lone lane's critical path (the affine
+    // conversions, the Fq12 inversion of the pairing); divergent, so wave-wide uses prefer inv_fermat.
+    // Works on the canonical Montgomery residue m = aR as a plain integer: m^-1 = a^-1 R^-1, and one product with R^3
+    // gives a^-1 R.  inv(0) = 0.  The loop is bounded, so every lane leaves it.
     H2V_FN Fp inv() const {
         if (is_zero()) return zero();
         uint32_t u[8], w[8], x1[8], x2[8];
-        for (int i = 0; i < 8; ++i) { u[i] = v[i]; w[i] = PR::P(i); x1[i] = i == 0 ? 1u : 0u; x2[i] = 0u; }
+        { uint32_t c[9]; canonical(c); unpack29(u, c); }
+        for (int i = 0; i < 8; ++i) { w[i] = PR::P(i); x1[i] = i == 0 ? 1u : 0u; x2[i] = 0u; }
         auto is_one = [](const uint32_t a[8]) { uint32_t o = a[0] ^ 1u; for (int i = 1; i < 8; ++i) o |= a[i]; return o == 0; };
         auto shr1 = [](uint32_t a[8], uint32_t top) { for (int i = 0; i < 7; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31); a[7] = (a[7] >> 1) | (top << 31); };
         auto halve_mod = [&](uint32_t x[8]) {  // x <- x / 2 mod p
@@ -255,8 +368,8 @@ template <class PR> struct Fp {
             else { sub_raw(w, u); sub_mod(x2, x1); shr1(w, 0); halve_mod(x2); }
         }
         Fp t, r3;
-        const bool from_u = is_one(u);
-        for (int i = 0; i < 8; ++i) { t.v[i] = from_u ? x1[i] : x2[i]; r3.v[i] = PR::R3(i); }
+        pack29(t.v, is_one(u) ? x1 : x2);
+        for (int i = 0; i < 9; ++i) r3.v[i] = PR::R3(i);
         return mul(t, r3);
     }
     H2V_HD bool is_odd() const { uint32_t raw[8]; to_raw(raw); return raw[0] & 1; }

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const M
                 if (!nz) continue;  // zero scalar (e.g. a point slot the channel does not use)
                 const uint32_t* bw = reinterpret_cast<const uint32_t*>(t < pq.n1 ? pq.bases + (size_t)pq.bstride * t : pq.bases2 + (size_t)pq.bstride * (t - pq.n1));
                 uint32_t any = 0;
-                for (int i = 0; i < 16; ++i) any |= bw[i];
+                for (int i = 0; i < (int)(sizeof(G1A) / 4); ++i) any |= bw[i];
                 if (!any) continue;  // identity bases contribute nothing
                 GlvHalf h[2];
                 glv_decompose(s, h[0], h[1]);
@@ -232,9 +232,8 @@ __device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) {
     const uint32_t t = e & MSM_ENTRY_TERM;
     G1A b = t < q.n1 ? q.bases[(size_t)t * q.bstride] : q.bases2[(size_t)(t - q.n1) * q.bstride];
     if (e & MSM_ENTRY_HALF) {
-        Fq beta;  // Montgomery form of the cube root of unity 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
-        beta.v[0] = 0x13e80b9cu; beta.v[1] = 0x3350c88eu; beta.v[2] = 0xdb5e56b9u; beta.v[3] = 0x7dce557cu;
-        beta.v[4] = 0xb615564au; beta.v[5] = 0x6001b4b8u; beta.v[6] = 0x020217e0u; beta.v[7] = 0x2682e617u;
+        // Montgomery form (29-bit limbs, R = 2^261) of the cube root of unity 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
+        const Fq beta = {{0x18ccb791u, 0x175b1c3au, 0x0b83d6e2u, 0x0e8ed071u, 0x1282bee2u, 0x04220e84u, 0x1fe4017fu, 0x15084d4au, 0x00169119u}};
         b.x = Fq::mul(b.x, beta);
     }
     if (e & MSM_ENTRY_NEG) b.y = b.y.neg();

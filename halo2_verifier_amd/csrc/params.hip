@@ -9,10 +9,10 @@
 namespace h2v {
 
 static Fq fq_from_mont_bytes(const uint8_t* b, bool& ok) {
-    Fq x;
-    for (int i = 0; i < 8; ++i) x.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
-    if (Fq::geq_p(x.v)) ok = false;
-    return x;
+    uint32_t m[8];
+    for (int i = 0; i < 8; ++i) m[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    if (Fq::geq_p(m)) ok = false;
+    return Fq::from_mont256(m);
 }
 
 static Fq2 fq2_xi() { return {Fq::from_u32(9), Fq::from_u32(1)}; }

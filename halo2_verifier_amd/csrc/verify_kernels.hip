@@ -262,16 +262,19 @@ __global__ void __launch_bounds__(1024) k_multipliers(const uint8_t* __restrict_
     }
 }
 
+// program slots are limb-planar: limb l of slot s of proof p is word (s * 9 + l) * n + p, so that a wave's 64 proofs read 64
+// consecutive words per limb
 __device__ __forceinline__ Fr slot_load(const Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p) {
-    const uint4* q = reinterpret_cast<const uint4*>(slots + (size_t)s * n + p);
-    uint4 lo = q[0], hi = q[1];
-    Fr r; r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w; r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(slots) + (size_t)s * H2V_LIMBS * n + p;
+    Fr r;
+#pragma unroll
+    for (int l = 0; l < H2V_LIMBS; ++l) r.v[l] = q[(size_t)l * n];
     return r;
 }
 __device__ __forceinline__ void slot_store(Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p, const Fr& v) {
-    uint4* q = reinterpret_cast<uint4*>(slots + (size_t)s * n + p);
-    q[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-    q[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+    uint32_t* q = reinterpret_cast<uint32_t*>(slots) + (size_t)s * H2V_LIMBS * n + p;
+#pragma unroll
+    for (int l = 0; l < H2V_LIMBS; ++l) q[(size_t)l * n] = v.v[l];
 }
 
 __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {

@@ -27,8 +27,10 @@ struct Reader {
 };
 
 template <class F> bool field_from_mont_bytes(const uint8_t* b, F& x) {
-    for (int i = 0; i < 8; ++i) x.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
-    return !F::geq_p(x.v);
+    uint32_t m[8];  // halo2curves' in-memory form: residue * 2^256 mod p
+    for (int i = 0; i < 8; ++i) m[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    x = F::from_mont256(m);
+    return !F::geq_p(m);
 }
 bool read_fr(Reader& r, int fmt, Fr& x, std::string& err) {
     const uint8_t* b = r.take(32);
@@ -136,7 +138,7 @@ struct Node { uint32_t op; Val a, b; uint32_t imm; bool has_result; };
 struct Builder {
     std::vector<Node> nodes;
     std::vector<Fr> consts;
-    std::map<std::array<uint32_t, 8>, Val> const_node;
+    std::map<std::array<uint32_t, 9>, Val> const_node;
     std::vector<int64_t> const_of;  // node id -> const index or -1
     std::map<uint32_t, Val> scalar_node, inst_node, chal_node;
     Val mult_node = (Val)-1;
@@ -148,7 +150,7 @@ struct Builder {
     bool is_const(Val v) const { return const_of[v] >= 0; }
     const Fr& cval(Val v) const { return consts[(size_t)const_of[v]]; }
     Val cst(const Fr& f) {
-        std::array<uint32_t, 8> key; for (int i = 0; i < 8; ++i) key[i] = f.v[i];
+        std::array<uint32_t, 9> key; f.canonical(key.data());
         auto it = const_node.find(key);
         if (it != const_node.end()) return it->second;
         consts.push_back(f);

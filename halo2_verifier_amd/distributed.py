@@ -2,7 +2,7 @@
 
 The reference has no communication layer.  Proofs are independent until the final
 pairing, so the batch is cut into contiguous shards; every rank runs the whole per-proof pipeline
-and its two pooled MSMs, and the only exchange is an all-gather of 2 G1 points (2 x 96 bytes) per
+and its two pooled MSMs, and the only exchange is an all-gather of 2 G1 points (2 x 108 bytes) per
 rank — RCCL has no user-defined reduction, and a group addition is not a numeric sum — followed
 by a 2(N-1)-addition fold and ONE pairing (DualMSM::add_msm + check, poly/kzg/msm.rs:178-203).
 
@@ -19,7 +19,7 @@ def shard_bounds(total: int, world_size: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-ACC_BYTES = 192  # 2 x Jacobian G1 (3 x 32 B Montgomery limbs)
+ACC_BYTES = 216  # 2 x Jacobian G1 (3 coordinates x 9 limbs x 4 B, the library's Montgomery limb layout)
 
 
 def gather_accumulators(local_acc, world_size, group=None):

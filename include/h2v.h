@@ -155,7 +155,7 @@ int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t
 int h2v_batch_set_groups(h2v_batch* b, size_t groups);
 /* As h2v_batch_finish for a grouped batch: group_ok[n_groups], out_left_xy / out_right_xy = n_groups x 64 bytes. */
 int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left_xy, uint8_t* out_right_xy, size_t n_groups);
-/* Device address of this batch's accumulator points after launch: per group [left, right], 2 x 96 bytes each, Jacobian
+/* Device address of this batch's accumulator points after launch: per group [left, right], 2 x 108 bytes each, Jacobian
  * (X, Y, Z) in the library's Montgomery limb layout — opaque bytes to be moved by a collective. */
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes);
 /* The HIP stream (hipStream_t) the batch runs on, for event timing and stream-ordered interop. */
@@ -164,7 +164,7 @@ void* h2v_batch_stream(h2v_batch* b);
  * so that collectives issued by the caller on that stream are ordered with the batch's kernels without
  * host synchronisation.  The caller keeps the stream alive while the batch uses it. */
 int h2v_batch_set_stream(h2v_batch* b, void* hip_stream);
-/* Stream-ordered copy of the accumulator points (groups x 2 x 96 bytes) into caller device memory. */
+/* Stream-ordered copy of the accumulator points (groups x 2 x 108 bytes) into caller device memory. */
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst);
 /* Stream-ordered version of h2v_fold_check on the batch's stream: fold n_parts gathered accumulator
  * sets (each laid out as h2v_batch_export_accumulators writes it: [group][left, right]) group by group and enqueue one
