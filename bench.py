@@ -5,8 +5,10 @@ One "step" = one pass of the whole hot path (point decompression -> Blake2b tran
 -> shared-base fold -> pooled MSMs -> one pairing) over one batch of `--batch` proofs PER GPU that is
 already resident in HBM.  N > 1: every rank verifies its own shard, the 2 accumulator points per rank
 are all-gathered over RCCL and folded, and a single pairing closes the whole N x batch step (weak scaling).
-Steps are pipelined over `--depth` batch objects (one HIP stream each) because the tail of a batch —
-window Horner, the pairing — is a single wave; all K timed steps start and finish inside the timed region.
+The tail of a step — window Horner, the pairing — is a handful of waves with millisecond-long dependent chains, so
+steps are issued `--groups` at a time as one grouped batch (h2v_batch_set_groups: every kernel runs once for all of
+them, each step keeps its own accumulators and its own pairing) and `--depth` such launches are in flight (one HIP
+stream each); all K timed steps start and finish inside the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the MSM stage (the kernel BASELINE.json names):
 achieved = 96 B x terms / mean MSM-stage time measured with HIP events on the batch's own stream.
@@ -80,10 +82,10 @@ def cpu_baseline(d, sample, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--groups", type=int, default=8, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups)")
+    ap.add_argument("--groups", type=int, default=16, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups)")
     ap.add_argument("--depth", type=int, default=8, help="launches in flight per GPU (one HIP stream each)")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
     ap.add_argument("--cpu-sample", type=int, default=2048)
