@@ -12,14 +12,19 @@
 //                   to reduce and half the doublings in the final Horner chain
 //   1. msm_count    one workgroup per tile of 1024 terms: signed digits of both GLV halves, histogram staged in LDS
 //                   (one LDS atomic per entry), one global atomic per non-empty (tile, bucket)
-//   2. msm_scan     exclusive prefix sum of the histogram (one workgroup)
+//   2. msm_block_sums / msm_scan_sums / msm_offsets
+//                   exclusive prefix sum of the histogram in three small launches (1024 bins per workgroup)
 //   3. msm_scatter  same tiles: LDS histogram again, one global atomic per (tile, bucket) reserves the tile's span of
 //                   the bucket's list, LDS atomics hand out positions inside it
-//   4. msm_bucket   one lane per bucket: mixed Jacobian+affine additions over its list;
-//                   buckets with more than max(64, 2 x average) entries are handed to
-//      msm_heavy    one workgroup per heavy bucket: strided partial sums + LDS tree.  (The top window of
-//                   a 254-bit scalar is only a few bits wide, so its few buckets each collect n/2^bits
-//                   terms — without this a single lane serialises hundreds of additions.)
+//   4. msm_accumulate  the sorted list is cut into CHUNKS OF EQUAL LENGTH (32 entries), one lane per chunk, whatever the
+//                   bucket boundaries: every lane does the same number of mixed additions, so a wave is not held up by its
+//                   fullest bucket (with ~13 entries per bucket on average a lane-per-bucket mapping idles ~45 % of the
+//                   lanes) and no bucket is ever too big for a lane (the top window of a 254-bit scalar is only a few bits
+//                   wide: its buckets collect hundreds of entries).  A bucket that lies inside one chunk is written
+//                   directly; the head and tail pieces of a chunk go to a side array and
+//      msm_fixup    one lane per bucket sums the pieces of a bucket that straddles chunks (buckets spread over more than
+//                   64 chunks — skewed inputs — go to msm_fixup_heavy, one workgroup each) and writes the identity for
+//                   empty buckets
 //   5. msm_window   one workgroup per (problem, window): sum_b (b+1) * bucket[b] by per-lane running sums
 //                   over a slice of buckets, then a tree reduction through LDS
 //   6. msm_final    one lane per problem: Horner over windows (c doublings + one add per window)
@@ -37,7 +42,8 @@
 
 namespace h2v {
 
-#define MSM_HEAVY_MIN 32u   // a bucket is 'heavy' when it holds more than max(this, 2 x the average) entries
+#define MSM_CHUNK 32u            // list entries per lane of msm_accumulate
+#define MSM_FIXUP_SERIAL 64u     // a bucket spread over more chunks than this is summed by a workgroup
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
@@ -61,14 +67,24 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     for (uint32_t n = 1; n <= max_per_problem; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n); mb = std::max(mb, (size_t)p.windows * p.buckets); }
     { MsmPlan p = msm_plan(max_per_problem); mb = std::max(mb, (size_t)p.windows * p.buckets); }
     mb *= max_problems;
-    cap_buckets = mb; cap_list = (size_t)max_terms * 130;  // c >= 2  =>  2 halves x <= 65 windows; max_terms = total terms over all problems
-    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 1) * 4));
+    cap_buckets = mb;
+    // list entries: 2 GLV halves x windows per term, for the plan of the largest problem of a launch
+    cap_list = 0;
+    for (uint32_t n = 1;; n = n < 16 ? n + 1 : n + n / 8) {
+        if (n > max_per_problem) n = max_per_problem;
+        size_t terms = std::min<size_t>(max_terms, (size_t)n * max_problems);
+        cap_list = std::max(cap_list, terms * 2 * msm_plan(n).windows);
+        if (n == max_per_problem) break;
+    }
+    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&cursor, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
     H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1J)));
     H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1J)));
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
+    H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
+    H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK + 1) * 2 * sizeof(G1J)));
     return 0;
 }
 void MsmWorkspace::release() {
@@ -79,7 +95,9 @@ void MsmWorkspace::release() {
     if (bucket_pts) hipFree(bucket_pts);
     if (window_sums) hipFree(window_sums);
     if (problems) hipFree(problems);
-    counts = offsets = cursor = list = nullptr; bucket_pts = window_sums = nullptr; problems = nullptr;
+    if (block_sums) hipFree(block_sums);
+    if (partial) hipFree(partial);
+    counts = offsets = cursor = list = block_sums = nullptr; bucket_pts = window_sums = partial = nullptr; problems = nullptr;
     cap_terms = 0; cap_problems = 0;
 }
 
@@ -240,15 +258,47 @@ __device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) {
     return b;
 }
 
-// exclusive scan of counts[0..nb) -> offsets; zeroes cursor.  One workgroup of 1024 lanes.
-__global__ void __launch_bounds__(1024) msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, uint32_t nb) {
+// Exclusive prefix sum of counts[0..nb) -> offsets (bin order, so that a list position can be mapped back to its bin by
+// binary search), in three launches: per-1024-bin sums, a scan of those sums by one workgroup, local scans + block base.
+// counts[nb + 1] receives the total number of list entries.  Also zeroes the scatter cursors.
+__global__ void __launch_bounds__(1024) msm_block_sums(const uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums, uint32_t nb) {
     __shared__ uint32_t part[1024];
-    uint32_t t = threadIdx.x;
-    uint32_t chunk = (nb + 1023) / 1024;
-    uint32_t lo = min(nb, t * chunk), hi = min(nb, lo + chunk);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += counts[i];
-    part[t] = sum;
+    const uint32_t t = threadIdx.x, i = blockIdx.x * 1024 + t;
+    part[t] = i < nb ? counts[i] : 0;
+    __syncthreads();
+    for (uint32_t d = 512; d > 0; d >>= 1) { if (t < d) part[t] += part[t + d]; __syncthreads(); }
+    if (t == 0) block_sums[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(1024) msm_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nblk, uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblk; base += 1024) {   // uniform trip count: no barrier is skipped
+        const uint32_t i = base + t;
+        const uint32_t c = i < nblk ? block_sums[i] : 0;
+        part[t] = c;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            uint32_t v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        if (i < nblk) block_sums[i] = carry + part[t] - c;
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) *total = carry;
+}
+__global__ void __launch_bounds__(1024) msm_offsets(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets,
+                                                    uint32_t* __restrict__ cursor, uint32_t nb) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, i = blockIdx.x * 1024 + t;
+    const uint32_t c = i < nb ? counts[i] : 0;
+    part[t] = c;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         uint32_t v = t >= d ? part[t - d] : 0;
@@ -256,55 +306,105 @@ __global__ void __launch_bounds__(1024) msm_scan(const uint32_t* __restrict__ co
         part[t] += v;
         __syncthreads();
     }
-    uint32_t run = part[t] - sum;
-    for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; cursor[i] = 0; }
+    if (i < nb) { offsets[i] = block_sums[blockIdx.x] + part[t] - c; cursor[i] = 0; }
 }
 
-// complete (slow, call-based) group law for the rare bucket in which a point meets itself or its negative
-__device__ __noinline__ void msm_bucket_slow(const MsmProblem q, const uint32_t* __restrict__ entries, uint32_t cnt, G1J* __restrict__ out) {
-    G1J acc = G1J::identity();
-    for (uint32_t i = 0; i < cnt; ++i) acc = g1_add_affine(acc, msm_entry_base(q, entries[i]));
-    *out = acc;
+// the bin that holds list position pos: the last b with offsets[b] <= pos (empty bins share the offset of the next non-empty one)
+__device__ __forceinline__ uint32_t msm_bin_of(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t pos) {
+    uint32_t lo = 0, hi = nb;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid; }
+    return lo;
 }
-__device__ __noinline__ void msm_slice_slow(const G1J* __restrict__ bp, uint32_t lo, uint32_t hi, uint32_t c, G1J* __restrict__ out) {
-    G1J run = G1J::identity(), sum = G1J::identity();
-    for (uint32_t b = hi; b > lo; --b) { run = g1_add(run, bp[b - 1]); sum = g1_add(sum, run); }
-    if (lo < hi && lo > 0) {
-        G1J scaled = G1J::identity();
-        for (int i = (int)c - 1; i >= 0; --i) { scaled = g1_dbl(scaled); if ((lo >> i) & 1) scaled = g1_add(scaled, run); }
-        sum = g1_add(sum, scaled);
+// Where the pieces of chunk `lane` go: a piece that is a whole bucket -> bucket_pts[b]; otherwise the chunk's first piece ->
+// partial[2*lane], its last -> partial[2*lane + 1] (a chunk has no other incomplete pieces).
+__device__ __forceinline__ G1J* msm_piece_dst(G1J* __restrict__ bucket_pts, G1J* __restrict__ partial, uint32_t lane, uint32_t b, uint32_t bin_lo, uint32_t bin_hi,
+                                              uint32_t chunk_lo, uint32_t chunk_hi, bool first) {
+    if (bin_lo >= chunk_lo && bin_hi <= chunk_hi) return bucket_pts + b;
+    return partial + 2 * (size_t)lane + (first ? 0 : 1);
+}
+// complete (slow, call-based) group law for the rare chunk in which a point meets itself or its negative
+__device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                            const uint32_t* __restrict__ list, G1J* __restrict__ bucket_pts, G1J* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E) {
+    const uint32_t chunk_lo = lane * MSM_CHUNK, chunk_hi = min(chunk_lo + MSM_CHUNK, E);
+    uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
+    uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
+    MsmProblem q = prs[b / nbq];
+    G1J acc = G1J::identity();
+    bool first = true;
+    for (uint32_t pos = chunk_lo; pos < chunk_hi;) {
+        acc = g1_add_affine(acc, msm_entry_base(q, list[pos]));
+        ++pos;
+        if (pos == bin_hi || pos == chunk_hi) {
+            *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
+            acc = G1J::identity(); first = false;
+            if (pos == bin_hi && pos < chunk_hi) {
+                do { ++b; } while (counts[b] == 0);
+                bin_lo = bin_hi; bin_hi = bin_lo + counts[b];
+                q = prs[b / nbq];
+            }
+        }
     }
-    *out = sum;
+}
+__global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ list, G1J* __restrict__ bucket_pts, G1J* __restrict__ partial, uint32_t nb) {
+    const uint32_t E = counts[nb + 1];
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t chunk_lo = lane * MSM_CHUNK;
+    if (chunk_lo >= E) return;
+    const uint32_t chunk_hi = min(chunk_lo + MSM_CHUNK, E);
+    uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
+    uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
+    uint32_t qi = b / nbq;
+    MsmProblem q = prs[qi];
+    G1J acc = G1J::identity();
+    bool first = true, ok = true;
+    for (uint32_t pos = chunk_lo; pos < chunk_hi && ok;) {
+        ok = g1_madd_fast(acc, msm_entry_base(q, list[pos]));
+        ++pos;
+        if (pos == bin_hi || pos == chunk_hi) {
+            if (ok) *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
+            acc = G1J::identity(); first = false;
+            if (pos == bin_hi && pos < chunk_hi) {
+                do { ++b; } while (counts[b] == 0);   // pos < E: a later non-empty bin exists
+                bin_lo = bin_hi; bin_hi = bin_lo + counts[b];
+                const uint32_t qn = b / nbq;
+                if (qn != qi) { qi = qn; q = prs[qi]; }
+            }
+        }
+    }
+    if (!ok) msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E);  // redo the chunk with complete formulas
 }
 
+// the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
+__device__ __forceinline__ const G1J* msm_piece_src(const G1J* __restrict__ partial, uint32_t i, uint32_t i0, uint32_t off) {
+    return partial + 2 * (size_t)i + ((i == i0 && off > i0 * MSM_CHUNK) ? 1 : 0);
+}
 // after the scatter `cursor` is free: it becomes the list of heavy buckets, counts[nb] their number
-__global__ void __launch_bounds__(64) msm_bucket(const MsmProblem* __restrict__ prs, uint32_t nbq, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                 const uint32_t* __restrict__ list, uint32_t* __restrict__ heavy, G1J* __restrict__ bucket_pts, uint32_t nb, uint32_t heavy_threshold) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1J* __restrict__ partial,
+                                                uint32_t* __restrict__ heavy, G1J* __restrict__ bucket_pts, uint32_t nb) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    uint32_t cnt = counts[b], off = offsets[b];
-    if (cnt > heavy_threshold) { heavy[atomicAdd(&counts[nb], 1u)] = b; return; }
-    const MsmProblem q = prs[b / nbq];
-    G1J acc = G1J::identity();
-    bool ok = true;
-    for (uint32_t i = 0; i < cnt && ok; ++i) ok = g1_madd_fast(acc, msm_entry_base(q, list[off + i]));
-    if (!ok) { msm_bucket_slow(q, list + off, cnt, bucket_pts + b); return; }  // a base met itself or its negative
+    const uint32_t cnt = counts[b], off = offsets[b];
+    if (cnt == 0) { bucket_pts[b] = G1J::identity(); return; }
+    const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
+    if (i0 == i1) return;  // written whole by its chunk
+    if (i1 - i0 >= MSM_FIXUP_SERIAL) { heavy[atomicAdd(&counts[nb], 1u)] = b; return; }
+    G1J acc = *msm_piece_src(partial, i0, i0, off);
+    for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off));
     bucket_pts[b] = acc;
 }
-
-__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_heavy(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ heavy,
-                                                               G1J* __restrict__ bucket_pts, uint32_t nb) {
+__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1J* __restrict__ partial,
+                                                                     const uint32_t* __restrict__ heavy, G1J* __restrict__ bucket_pts, uint32_t nb) {
     __shared__ G1J red[MSM_HEAVY_THREADS];
-    uint32_t n_heavy = counts[nb];
-    uint32_t t = threadIdx.x;
+    const uint32_t n_heavy = counts[nb];
+    const uint32_t t = threadIdx.x;
     // every workgroup reaches the exit condition: the heavy list is complete before this kernel starts
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        uint32_t b = heavy[h];
-        uint32_t cnt = counts[b], off = offsets[b];
-        const MsmProblem q = prs[b / nbq];
+        const uint32_t b = heavy[h];
+        const uint32_t cnt = counts[b], off = offsets[b];
+        const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
         G1J acc = G1J::identity();
-        for (uint32_t i = t; i < cnt; i += MSM_HEAVY_THREADS) acc = g1_add_affine(acc, msm_entry_base(q, list[off + i]));
+        for (uint32_t i = i0 + t; i <= i1; i += MSM_HEAVY_THREADS) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off));
         red[t] = acc;
         __syncthreads();
         for (uint32_t d = MSM_HEAVY_THREADS / 2; d > 0; d >>= 1) {
@@ -314,6 +414,18 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_heavy(const MsmProblem*
         if (t == 0) bucket_pts[b] = red[0];
         __syncthreads();
     }
+}
+
+// complete formulas for the rare window slice in which a running sum meets an equal or opposite point
+__device__ __noinline__ void msm_slice_slow(const G1J* __restrict__ bp, uint32_t lo, uint32_t hi, uint32_t c, G1J* __restrict__ out) {
+    G1J run = G1J::identity(), sum = G1J::identity();
+    for (uint32_t b = hi; b > lo; --b) { run = g1_add(run, bp[b - 1]); sum = g1_add(sum, run); }
+    if (lo < hi && lo > 0) {
+        G1J scaled = G1J::identity();
+        for (int i = (int)c - 1; i >= 0; --i) { scaled = g1_dbl(scaled); if ((lo >> i) & 1) scaled = g1_add(scaled, run); }
+        sum = g1_add(sum, scaled);
+    }
+    *out = sum;
 }
 
 __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restrict__ bucket_pts, G1J* __restrict__ window_sums, MsmPlan p) {
@@ -388,18 +500,22 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     MsmPlan p = msm_plan(nmax);
     uint32_t nbq = p.windows * p.buckets, nb = nbq * count;
     if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
-    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 1) * 4, s));
+    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 2) * 4, s));
     dim3 gt((nmax + MSM_TILE - 1) / MSM_TILE, count);
     const uint32_t wpp = std::max<uint32_t>(1u, std::min<uint32_t>(p.windows, MSM_LDS_WORDS / p.buckets));
     const size_t lds = (size_t)wpp * p.buckets * 4;
     hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
-    hipLaunchKernelGGL(msm_scan, dim3(1), dim3(1024), 0, s, ws.counts, ws.offsets, ws.cursor, nb);
+    const uint32_t nblk = (nb + 1023) / 1024;
+    hipLaunchKernelGGL(msm_block_sums, dim3(nblk), dim3(1024), 0, s, ws.counts, ws.block_sums, nb);
+    hipLaunchKernelGGL(msm_scan_sums, dim3(1), dim3(1024), 0, s, ws.block_sums, nblk, ws.counts + nb + 1);
+    hipLaunchKernelGGL(msm_offsets, dim3(nblk), dim3(1024), 0, s, ws.counts, ws.block_sums, ws.offsets, ws.cursor, nb);
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
-    // with random scalars a bucket holds about 2n / buckets entries; outliers go to the workgroup path: skewed inputs, and the
-    // top window, whose digits span fewer bits (128 is not a multiple of c) so that its buckets collect several times the average
-    uint32_t heavy_threshold = std::max<uint32_t>(MSM_HEAVY_MIN, 2u * (uint32_t)((2ull * nmax + p.buckets - 1) / p.buckets));
-    hipLaunchKernelGGL(msm_bucket, dim3((nb + 63) / 64), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb, heavy_threshold);
-    hipLaunchKernelGGL(msm_heavy, dim3(512), dim3(MSM_HEAVY_THREADS), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.cursor, ws.bucket_pts, nb);
+    // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers its upper bound
+    const size_t max_entries = total * 2 * p.windows;
+    const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK - 1) / MSM_CHUNK);
+    hipLaunchKernelGGL(msm_accumulate, dim3((chunks + 63) / 64), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
+    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
+    hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
     hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
     H2V_HIP_CHECK(hipGetLastError());
