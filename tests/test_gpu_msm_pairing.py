@@ -46,6 +46,30 @@ def test_msm_matches_oracle(ctx, srs, oracle, n):
     assert ctx.msm_g1(scalars, bases) == oracle_lib.g1_msm(oracle, scalars, bases)
 
 
+@pytest.mark.parametrize("kind", ["one_scalar", "one_base", "same_term", "two_values", "small_scalars"])
+def test_msm_skewed_inputs(ctx, srs, oracle, kind):
+    """Inputs that defeat the 'random scalars' assumptions of the bucket method: one bucket per window holds every
+    entry (its pieces are spread over hundreds of accumulation chunks -> the workgroup fix-up), the same point meets
+    itself inside a chunk (the complete-formula fallback), and buckets whose partial sums coincide or cancel."""
+    rnd = random.Random({"one_scalar": 1, "one_base": 2, "same_term": 3, "two_values": 4, "small_scalars": 5}[kind])
+    n = 5000
+    pts = [g1_xy(p) for p in srs.g]
+    if kind == "one_scalar":        # every term in the same bucket of every window
+        k = rnd.randrange(R_MOD)
+        scalars, bases = [k] * n, [pts[rnd.randrange(srs.n)] for _ in range(n)]
+    elif kind == "one_base":        # buckets are multiples of one point: equal and opposite partial sums everywhere
+        scalars, bases = [rnd.randrange(R_MOD) for _ in range(n)], [pts[3]] * n
+    elif kind == "same_term":       # P + P in every chunk
+        scalars, bases = [0x1234567890abcdef1234567890abcdef] * n, [pts[9]] * n
+    elif kind == "two_values":
+        a, b = rnd.randrange(R_MOD), rnd.randrange(R_MOD)
+        scalars = [a if i % 3 else b for i in range(n)]
+        bases = [pts[i % 7] for i in range(n)]
+    else:                           # all windows above the first are empty
+        scalars, bases = [rnd.randrange(1, 200) for _ in range(n)], [pts[rnd.randrange(srs.n)] for _ in range(n)]
+    assert ctx.msm_g1(scalars, bases) == oracle_lib.g1_msm(oracle, scalars, bases)
+
+
 def test_msm_cancellation_gives_identity(ctx, srs):
     p = srs.g[7]
     q = (p[0], srs_util.P - p[1])
