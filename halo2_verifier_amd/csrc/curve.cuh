@@ -135,11 +135,44 @@ H2V_FN G1A g1_to_affine(const G1J& p) {
     return a;
 }
 
-// sqrt in Fq for p = 3 mod 4: a^((p+1)/4); caller checks r^2 == a
-H2V_FN Fq fq_sqrt_candidate(const Fq& a) {
+// sqrt in Fq for p = 3 mod 4: a^((p+1)/4); caller checks r^2 == a.
+// The exponent is a constant, so the whole sliding-window schedule (which odd power multiplies in after which run of
+// squarings) is computed at compile time and the loop below unrolls into straight-line calls: the table of odd powers
+// is indexed by constants only and stays in registers — a run-time-indexed table would live in scratch memory.
+struct FqSqrtSchedule { uint8_t op[300]; int n; };  // 0: square; k > 0: multiply by a^(2k-1)
+constexpr FqSqrtSchedule fq_sqrt_schedule() {
     // (p+1)/4 = 0x0c19139cb84c680a6e14116da060561765e05aa45a1c72a34f082305b61f3f52
-    const uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
-    return a.pow_limbs(e);
+    constexpr uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+    FqSqrtSchedule s{};
+    s.n = 0;
+    int i = 255;
+    while (i >= 0 && !((e[i >> 5] >> (i & 31)) & 1)) --i;
+    while (i >= 0) {
+        if (!((e[i >> 5] >> (i & 31)) & 1)) { s.op[s.n++] = 0; --i; continue; }
+        int l = i - 3 < 0 ? 0 : i - 3;                       // window of at most 4 bits ending in a set bit
+        while (!((e[l >> 5] >> (l & 31)) & 1)) ++l;
+        uint32_t v = 0;
+        for (int k = i; k >= l; --k) { v = (v << 1) | ((e[k >> 5] >> (k & 31)) & 1); s.op[s.n++] = 0; }
+        s.op[s.n++] = (uint8_t)((v + 1) / 2);
+        i = l - 1;
+    }
+    return s;
+}
+H2V_FN Fq fq_sqrt_candidate(const Fq& a) {
+    constexpr FqSqrtSchedule S = fq_sqrt_schedule();
+    Fq t[8];
+    t[0] = a;
+    const Fq a2 = a.sqr();
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t[k] = t[k - 1] * a2;
+    Fq r = Fq::one();
+    bool started = false;  // squarings of the leading 1 are skipped (resolved at compile time once unrolled)
+#pragma unroll
+    for (int k = 0; k < S.n; ++k) {
+        if (S.op[k] == 0) { if (started) r = r.sqr(); }
+        else { r = started ? r * t[S.op[k] - 1] : t[S.op[k] - 1]; started = true; }
+    }
+    return r;
 }
 
 // G1Affine::from_bytes (compressed).  Returns false for an invalid encoding.
