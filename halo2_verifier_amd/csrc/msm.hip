@@ -25,8 +25,8 @@
 //      msm_fixup    one lane per bucket sums the pieces of a bucket that straddles chunks (buckets spread over more than
 //                   64 chunks — skewed inputs — go to msm_fixup_heavy, one workgroup each) and writes the identity for
 //                   empty buckets
-//   5. msm_window   one workgroup per (problem, window): sum_b (b+1) * bucket[b] by per-lane running sums
-//                   over a slice of buckets, then a tree reduction through LDS
+//   5. msm_window   one wave (four for more than 2048 buckets) per (problem, window): sum_b (b+1) * bucket[b] by per-lane
+//                   running sums over a slice of buckets, then a tree reduction through LDS
 //   6. msm_final    one lane per problem: Horner over windows (c doublings + one add per window)
 //
 // Steps 1-3 are a hand-written counting sort (no atomics on points, no library sort); the only
@@ -47,13 +47,21 @@ namespace h2v {
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
+// lanes that share a window's bucket reduction: one wave up to 2048 buckets, four beyond
+static inline uint32_t msm_window_threads(uint32_t buckets) { return buckets <= 64 ? std::max(1u, buckets) : (buckets <= 2048 ? 64u : 256u); }
+
+// Window width by a cost model in Fq products: 2n mixed additions (11) per window, and per window the reduction
+// sum_b (b+1) B_b done by T lanes: 2 * slice running-sum additions, a c-bit double-and-add to weight the slice, a log2(T)
+// tree — full additions (16 products), T lanes wide.
 MsmPlan msm_plan(uint32_t n) {
     MsmPlan best{n, 2, 65, 2};
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 15; ++c) {
         uint32_t w = (130 + c - 1) / c;        // magnitudes < 2^128 (+1 bit of slack) + the carry of the signed recoding
         uint32_t b = 1u << (c - 1);
-        double cost = (double)w * (2.0 * n + 2.0 * b);
+        uint32_t T = msm_window_threads(b), slice = (b + T - 1) / T;
+        double lg = 0; for (uint32_t t = T; t > 1; t >>= 1) lg += 1;
+        double cost = (double)w * (11.0 * 2.0 * n + 16.0 * T * (2.0 * slice + 1.5 * c + 1.0 + lg));
         if (cost < best_cost) { best_cost = cost; best = MsmPlan{n, c, w, b}; }
     }
     return best;
@@ -430,9 +438,9 @@ __device__ __noinline__ void msm_slice_slow(const G1J* __restrict__ bp, uint32_t
 
 __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restrict__ bucket_pts, G1J* __restrict__ window_sums, MsmPlan p) {
     __shared__ G1J red[MSM_WIN_THREADS];
-    uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x;
-    uint32_t slice = (p.buckets + MSM_WIN_THREADS - 1) / MSM_WIN_THREADS;
-    uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
+    const uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x, T = blockDim.x;   // T: a power of two (msm_window_threads)
+    const uint32_t slice = (p.buckets + T - 1) / T;
+    const uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
     G1J run = G1J::identity(), sum = G1J::identity();
     const G1J* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
     bool ok = true;
@@ -452,7 +460,7 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restr
     if (ok) red[t] = sum;
     else msm_slice_slow(bp, lo, hi, p.c, &red[t]);  // degenerate meeting of equal / opposite points: complete formulas
     __syncthreads();
-    for (uint32_t d = MSM_WIN_THREADS / 2; d > 0; d >>= 1) {
+    for (uint32_t d = T / 2; d > 0; d >>= 1) {
         if (t < d) red[t] = g1_add(red[t], red[t + d]);
         __syncthreads();
     }
@@ -516,7 +524,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_accumulate, dim3((chunks + 63) / 64), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
-    hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(MSM_WIN_THREADS), 0, s, ws.bucket_pts, ws.window_sums, p);
+    hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(msm_window_threads(p.buckets)), 0, s, ws.bucket_pts, ws.window_sums, p);
     hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
