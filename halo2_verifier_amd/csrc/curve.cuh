@@ -41,12 +41,13 @@ struct G1J {
 // registers, and plain functions (real calls) for everything else.  Field products are inlined in both (see Fp::mul).
 H2V_FN G1J g1_dbl(const G1J& p);
 #define H2V_M(a, b) Fq::mul_inl((a), (b))
+#define H2V_S(a) (a).sqr_inl()
 __host__ __device__ __forceinline__ G1J g1_dbl_inl(const G1J& p) {
     if (p.is_identity()) return p;
-    Fq A = H2V_M(p.X, p.X), B = H2V_M(p.Y, p.Y), YZ = H2V_M(p.Y, p.Z);
-    Fq C = H2V_M(B, B), XB = p.X + B;
-    Fq D = (H2V_M(XB, XB) - A - C).dbl();
-    Fq E = A.dbl() + A, F = H2V_M(E, E);
+    Fq A = H2V_S(p.X), B = H2V_S(p.Y), YZ = H2V_M(p.Y, p.Z);
+    Fq C = H2V_S(B), XB = p.X + B;
+    Fq D = (H2V_S(XB) - A - C).dbl();
+    Fq E = A.dbl() + A, F = H2V_S(E);
     G1J r;
     r.X = F - D.dbl();
     r.Y = H2V_M(E, D - r.X) - C.dbl().dbl().dbl();
@@ -57,37 +58,37 @@ __host__ __device__ __forceinline__ G1J g1_dbl_inl(const G1J& p) {
 __host__ __device__ __forceinline__ G1J g1_add_inl(const G1J& p, const G1J& q) {
     if (p.is_identity()) return q;
     if (q.is_identity()) return p;
-    Fq Z1Z1 = H2V_M(p.Z, p.Z), Z2Z2 = H2V_M(q.Z, q.Z);
+    Fq Z1Z1 = H2V_S(p.Z), Z2Z2 = H2V_S(q.Z);
     Fq U1 = H2V_M(p.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
     Fq S1 = H2V_M(H2V_M(p.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, p.Z), Z1Z1);
     if (U1 == U2) {
         if (S1 == S2) { G1J t = p; return g1_dbl(t); }  // rare; a copy is passed so that the caller's accumulator never has its address taken (it stays in registers)
         return G1J::identity();
     }
-    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_M(H2, H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
+    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_S(H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
     Fq ZZ = p.Z + q.Z;
     G1J r;
-    r.X = H2V_M(rr, rr) - J - V.dbl();
+    r.X = H2V_S(rr) - J - V.dbl();
     r.Y = H2V_M(rr, V - r.X) - H2V_M(S1, J).dbl();
-    r.Z = H2V_M(H2V_M(ZZ, ZZ) - Z1Z1 - Z2Z2, H);
+    r.Z = H2V_M(H2V_S(ZZ) - Z1Z1 - Z2Z2, H);
     return r;
 }
 
 __host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1A& q) {
     if (q.is_identity()) return p;
     if (p.is_identity()) return G1J::from_affine(q);
-    Fq Z1Z1 = H2V_M(p.Z, p.Z);
+    Fq Z1Z1 = H2V_S(p.Z);
     Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, p.Z), Z1Z1);
     if (p.X == U2) {
         if (p.Y == S2) { G1J t = p; return g1_dbl(t); }  // rare; see g1_add_inl
         return G1J::identity();
     }
-    Fq H = U2 - p.X, HH = H2V_M(H, H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - p.Y).dbl(), V = H2V_M(p.X, I);
+    Fq H = U2 - p.X, HH = H2V_S(H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - p.Y).dbl(), V = H2V_M(p.X, I);
     Fq ZH = p.Z + H;
     G1J r;
-    r.X = H2V_M(rr, rr) - J - V.dbl();
+    r.X = H2V_S(rr) - J - V.dbl();
     r.Y = H2V_M(rr, V - r.X) - H2V_M(p.Y, J).dbl();
-    r.Z = H2V_M(ZH, ZH) - Z1Z1 - HH;
+    r.Z = H2V_S(ZH) - Z1Z1 - HH;
     return r;
 }
 
@@ -97,29 +98,29 @@ __host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1
 __host__ __device__ __forceinline__ bool g1_madd_fast(G1J& acc, const G1A& q) {
     if (q.is_identity()) return true;
     if (acc.is_identity()) { acc.X = q.x; acc.Y = q.y; acc.Z = Fq::one(); return true; }
-    Fq Z1Z1 = H2V_M(acc.Z, acc.Z);
+    Fq Z1Z1 = H2V_S(acc.Z);
     Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, acc.Z), Z1Z1);
     if (acc.X == U2) return false;
-    Fq H = U2 - acc.X, HH = H2V_M(H, H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - acc.Y).dbl(), V = H2V_M(acc.X, I);
+    Fq H = U2 - acc.X, HH = H2V_S(H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - acc.Y).dbl(), V = H2V_M(acc.X, I);
     Fq ZH = acc.Z + H;
-    Fq X3 = H2V_M(rr, rr) - J - V.dbl();
+    Fq X3 = H2V_S(rr) - J - V.dbl();
     Fq Y3 = H2V_M(rr, V - X3) - H2V_M(acc.Y, J).dbl();
-    acc.Z = H2V_M(ZH, ZH) - Z1Z1 - HH;
+    acc.Z = H2V_S(ZH) - Z1Z1 - HH;
     acc.X = X3; acc.Y = Y3;
     return true;
 }
 __host__ __device__ __forceinline__ bool g1_add_fast(G1J& acc, const G1J& q) {
     if (q.is_identity()) return true;
     if (acc.is_identity()) { acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z; return true; }
-    Fq Z1Z1 = H2V_M(acc.Z, acc.Z), Z2Z2 = H2V_M(q.Z, q.Z);
+    Fq Z1Z1 = H2V_S(acc.Z), Z2Z2 = H2V_S(q.Z);
     Fq U1 = H2V_M(acc.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
     if (U1 == U2) return false;
     Fq S1 = H2V_M(H2V_M(acc.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, acc.Z), Z1Z1);
-    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_M(H2, H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
+    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_S(H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
     Fq ZZ = acc.Z + q.Z;
-    Fq X3 = H2V_M(rr, rr) - J - V.dbl();
+    Fq X3 = H2V_S(rr) - J - V.dbl();
     Fq Y3 = H2V_M(rr, V - X3) - H2V_M(S1, J).dbl();
-    acc.Z = H2V_M(H2V_M(ZZ, ZZ) - Z1Z1 - Z2Z2, H);
+    acc.Z = H2V_M(H2V_S(ZZ) - Z1Z1 - Z2Z2, H);
     acc.X = X3; acc.Y = Y3;
     return true;
 }

@@ -253,10 +253,13 @@ __global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const M
     }
 }
 
-// the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y)
-__device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) {
+// the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y) — split into the load and the fix-up so that
+// the load of the next entry can be issued before the additions of the current one
+__device__ __forceinline__ G1A msm_entry_load(const MsmProblem& q, uint32_t e) {
     const uint32_t t = e & MSM_ENTRY_TERM;
-    G1A b = t < q.n1 ? q.bases[(size_t)t * q.bstride] : q.bases2[(size_t)(t - q.n1) * q.bstride];
+    return t < q.n1 ? q.bases[(size_t)t * q.bstride] : q.bases2[(size_t)(t - q.n1) * q.bstride];
+}
+__device__ __forceinline__ G1A msm_entry_apply(G1A b, uint32_t e) {
     if (e & MSM_ENTRY_HALF) {
         // Montgomery form (29-bit limbs, R = 2^261) of the cube root of unity 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
         const Fq beta = {{0x18ccb791u, 0x175b1c3au, 0x0b83d6e2u, 0x0e8ed071u, 0x1282bee2u, 0x04220e84u, 0x1fe4017fu, 0x15084d4au, 0x00169119u}};
@@ -265,6 +268,7 @@ __device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) {
     if (e & MSM_ENTRY_NEG) b.y = b.y.neg();
     return b;
 }
+__device__ __forceinline__ G1A msm_entry_base(const MsmProblem& q, uint32_t e) { return msm_entry_apply(msm_entry_load(q, e), e); }
 
 // Exclusive prefix sum of counts[0..nb) -> offsets (bin order, so that a list position can be mapped back to its bin by
 // binary search), in three launches: per-1024-bin sums, a scan of those sums by one workgroup, local scans + block base.
@@ -366,19 +370,30 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
     MsmProblem q = prs[qi];
     G1J acc = G1J::identity();
     bool first = true, ok = true;
+    // software pipeline: the (random-access) load of entry pos + 1 is in flight during the ~2500 instructions of addition pos
+    uint32_t e_next = list[chunk_lo];
+    G1A raw_next = msm_entry_load(q, e_next);
     for (uint32_t pos = chunk_lo; pos < chunk_hi && ok;) {
-        ok = g1_madd_fast(acc, msm_entry_base(q, list[pos]));
+        const uint32_t e = e_next;
+        const G1A raw = raw_next;
         ++pos;
-        if (pos == bin_hi || pos == chunk_hi) {
+        const bool flush = pos == bin_hi || pos == chunk_hi;
+        // bin (and problem) of the next entry
+        uint32_t b_next = b, lo_next = bin_lo, hi_next = bin_hi;
+        if (pos == bin_hi && pos < chunk_hi) {
+            do { ++b_next; } while (counts[b_next] == 0);   // pos < E: a later non-empty bin exists
+            lo_next = bin_hi; hi_next = lo_next + counts[b_next];
+        }
+        const uint32_t qn = b_next / nbq;
+        MsmProblem q_next = q;
+        if (qn != qi) q_next = prs[qn];
+        if (pos < chunk_hi) { e_next = list[pos]; raw_next = msm_entry_load(q_next, e_next); }
+        ok = g1_madd_fast(acc, msm_entry_apply(raw, e));
+        if (flush) {
             if (ok) *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
             acc = G1J::identity(); first = false;
-            if (pos == bin_hi && pos < chunk_hi) {
-                do { ++b; } while (counts[b] == 0);   // pos < E: a later non-empty bin exists
-                bin_lo = bin_hi; bin_hi = bin_lo + counts[b];
-                const uint32_t qn = b / nbq;
-                if (qn != qi) { qi = qn; q = prs[qi]; }
-            }
         }
+        b = b_next; bin_lo = lo_next; bin_hi = hi_next; qi = qn; q = q_next;
     }
     if (!ok) msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E);  // redo the chunk with complete formulas
 }
