@@ -211,6 +211,18 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # Outside the timed region: a few launches with ONE launch in flight, so that the HIP-event stage times are those of
+    # the kernels alone (with `depth` launches in flight a stage's elapsed time includes other streams' kernels).  The
+    # roofline figure uses these undisturbed durations; they agree with the rocprofv3 depth-1 summary under profiles/.
+    pipelined = dict(stage_sum), stage_cnt
+    stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
+    stage_cnt = 0
+    if world == 1:
+        for _ in range(4):
+            submit(0)
+            retire(0, True)
+    isolated = {k2: v / max(stage_cnt, 1) for k2, v in stage_sum.items()}
+    stage_sum, stage_cnt = pipelined
 
     if rank == 0:
         stages = {k2: v / max(stage_cnt, 1) for k2, v in stage_sum.items()}
@@ -219,7 +231,7 @@ def main():
         # over the batch (fixed + permutation commitments + g) + one h2 term per proof (left channel)
         n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
         terms_total = G * (n_local * shape["n_points"] + n_shared + n_local)
-        msm_ms = stages["msm"]
+        msm_ms = isolated["msm"] if world == 1 else stages["msm"]
         # HBM traffic of the MSM stage per launch comes from the committed PMC profile of this same workload
         # (separate rocprofv3 --pmc passes cannot run inside the timed region); null if it does not match this shape
         traffic = None
@@ -248,9 +260,14 @@ def main():
                                    f"{G} steps per launch (grouped batch), {depth} launches in flight",
                        "proofs_per_gpu_per_step": B, "steps_per_launch": G, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "MSM stage (msm_count/scan/scatter/bucket/heavy/window/final, both channels of every step of a launch)", "terms_per_launch": terms_total,
-                         "mean_stage_ms": msm_ms},
+                         "kernel": "MSM stage (msm_count, prefix sum, msm_scatter, msm_accumulate, msm_fixup, msm_window, msm_final; both channels of every step of a launch)", "terms_per_launch": terms_total,
+                         "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if world == 1 else "HIP events, pipelined",
+                         "alu": {"note": "the stage is bound by 32-bit integer multiply issue, not by HBM: achieved Fq products/s of the stage against the "
+                                         "measured chip-wide peak of the Montgomery product (tools/limb29_microbench.hip)",
+                                 "fq_products_per_term": 2 * 12 * 11, "achieved_Gprod_s": (2 * 12 * 11 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0,
+                                 "peak_Gprod_s": 168.0}},
             "stages_ms": stages,
+            "stages_ms_one_launch_in_flight": isolated if world == 1 else None,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline({**d, "proofs": (d["proofs"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 1024],

@@ -39,6 +39,9 @@ extern "C" {
                             n_instance_columns: usize, col_lens: *const usize, rand32_tail: *const u8, n_tail: usize) -> c_int;
     pub fn h2v_batch_launch(b: *mut h2v_batch, with_pairing: c_int) -> c_int;
     pub fn h2v_batch_finish(b: *mut h2v_batch, per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+    pub fn h2v_batch_set_groups(b: *mut h2v_batch, groups: usize) -> c_int;
+    pub fn h2v_batch_finish_groups(b: *mut h2v_batch, per_proof_status: *mut c_int, group_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8,
+                                   n_groups: usize) -> c_int;
     pub fn h2v_batch_export_accumulators(b: *mut h2v_batch, device_dst: *mut c_void) -> c_int;
     pub fn h2v_batch_fold_check_enqueue(b: *mut h2v_batch, device_accumulators: *const c_void, n_parts: usize) -> c_int;
     pub fn h2v_batch_set_stream(b: *mut h2v_batch, hip_stream: *mut c_void) -> c_int;
