@@ -46,17 +46,25 @@ struct MsmProblem {
 struct MsmProblemChunk { MsmProblem p[MSM_PROBLEM_CHUNK]; };
 struct MsmProblems { std::vector<MsmProblem> p; };
 
+// A Jacobian point in its own 128-byte line: the MSM's intermediate arrays are written once per lane at scattered
+// indices, and a 108-byte object that straddles lines costs partial-line writes on both (measured 2.5x the bytes)
+struct alignas(128) G1JSlot {
+    G1J p;
+    __host__ __device__ G1JSlot& operator=(const G1J& v) { p = v; return *this; }
+    __host__ __device__ operator const G1J&() const { return p; }
+};
+
 struct MsmWorkspace {
     uint32_t cap_terms = 0, cap_problems = 0;
     uint32_t* counts = nullptr;   // [problems * windows * buckets + 2]  (last two words: number of heavy buckets, list cursor)
     uint32_t* offsets = nullptr;  // [problems * windows * buckets]
     uint32_t* cursor = nullptr;   // scatter cursors, then the heavy-bucket list
     uint32_t* list = nullptr;     // term indices sorted by (problem, window, bucket)
-    G1J* bucket_pts = nullptr;    // [problems * windows * buckets]
-    G1J* window_sums = nullptr;   // [problems * windows]
+    G1JSlot* bucket_pts = nullptr;  // [problems * windows * buckets]
+    G1JSlot* window_sums = nullptr; // [problems * windows]
     MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
-    G1J* partial = nullptr;          // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
+    G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
     size_t cap_buckets = 0, cap_list = 0;
     // max_terms_per_problem sizes the bucket arrays (the window plan follows the largest problem of a launch)
     int alloc(uint32_t max_total_terms, uint32_t max_problems, uint32_t max_terms_per_problem = 0);

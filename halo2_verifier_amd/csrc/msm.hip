@@ -88,11 +88,11 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&cursor, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
-    H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1J)));
-    H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1J)));
+    H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
-    H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK + 1) * 2 * sizeof(G1J)));
+    H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK + 1) * 2 * sizeof(G1JSlot)));
     return 0;
 }
 void MsmWorkspace::release() {
@@ -191,10 +191,14 @@ __device__ __forceinline__ uint32_t raw_window(const uint32_t m[5], uint32_t w, 
 #define MSM_LDS_WORDS 16384u   // 64 KB of histogram per workgroup: as many windows per pass as fit
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const MsmProblem* __restrict__ prs, MsmPlan p, uint32_t windows_per_pass, uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const MsmProblem* __restrict__ prs, uint32_t n_problems, uint32_t tiles_per_problem, MsmPlan p, uint32_t windows_per_pass, uint32_t* __restrict__ counts,
                                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
     extern __shared__ uint32_t hist[];  // [windows_per_pass][buckets]
-    const uint32_t q = blockIdx.y, tile0 = blockIdx.x * MSM_TILE, tid = threadIdx.x;
+    // 1-D grid of 8 * ceil(problems / 8) * tiles workgroups; XCD x (= blockIdx % 8) takes the x-th eighth of the problems, so
+    // that the bins and the list spans a problem's tiles write to stay in one L2 and partial-line stores merge there
+    const uint32_t tiles = tiles_per_problem, per_xcd = (n_problems + 7) / 8;
+    const uint32_t q = (blockIdx.x % 8) * per_xcd + (blockIdx.x / 8) / tiles, tile0 = ((blockIdx.x / 8) % tiles) * MSM_TILE, tid = threadIdx.x;
+    if (q >= n_problems) return;  // whole workgroup
     const MsmProblem pq = prs[q];
     const uint32_t n = pq.n;
     if (tile0 >= n) return;  // whole workgroup: no barrier is skipped by part of a group
@@ -329,14 +333,14 @@ __device__ __forceinline__ uint32_t msm_bin_of(const uint32_t* __restrict__ offs
 }
 // Where the pieces of chunk `lane` go: a piece that is a whole bucket -> bucket_pts[b]; otherwise the chunk's first piece ->
 // partial[2*lane], its last -> partial[2*lane + 1] (a chunk has no other incomplete pieces).
-__device__ __forceinline__ G1J* msm_piece_dst(G1J* __restrict__ bucket_pts, G1J* __restrict__ partial, uint32_t lane, uint32_t b, uint32_t bin_lo, uint32_t bin_hi,
+__device__ __forceinline__ G1JSlot* msm_piece_dst(G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t lane, uint32_t b, uint32_t bin_lo, uint32_t bin_hi,
                                               uint32_t chunk_lo, uint32_t chunk_hi, bool first) {
     if (bin_lo >= chunk_lo && bin_hi <= chunk_hi) return bucket_pts + b;
     return partial + 2 * (size_t)lane + (first ? 0 : 1);
 }
 // complete (slow, call-based) group law for the rare chunk in which a point meets itself or its negative
 __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                            const uint32_t* __restrict__ list, G1J* __restrict__ bucket_pts, G1J* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E) {
+                                            const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E) {
     const uint32_t chunk_lo = lane * MSM_CHUNK, chunk_hi = min(chunk_lo + MSM_CHUNK, E);
     uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
     uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
@@ -358,9 +362,14 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
     }
 }
 __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ list, G1J* __restrict__ bucket_pts, G1J* __restrict__ partial, uint32_t nb) {
+                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb) {
     const uint32_t E = counts[nb + 1];
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
+    // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
+    // each) instead of all of them (15 MB per 16-step launch): the gathers hit in L2 instead of going out to the fabric.
+    const uint32_t blocks = ((E + MSM_CHUNK - 1) / MSM_CHUNK + 63) / 64, per_xcd = (blocks + 7) / 8;
+    if (blockIdx.x / 8 >= per_xcd) return;
+    const uint32_t lane = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * 64 + threadIdx.x;
     const uint32_t chunk_lo = lane * MSM_CHUNK;
     if (chunk_lo >= E) return;
     const uint32_t chunk_hi = min(chunk_lo + MSM_CHUNK, E);
@@ -399,12 +408,12 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
-__device__ __forceinline__ const G1J* msm_piece_src(const G1J* __restrict__ partial, uint32_t i, uint32_t i0, uint32_t off) {
+__device__ __forceinline__ const G1JSlot* msm_piece_src(const G1JSlot* __restrict__ partial, uint32_t i, uint32_t i0, uint32_t off) {
     return partial + 2 * (size_t)i + ((i == i0 && off > i0 * MSM_CHUNK) ? 1 : 0);
 }
 // after the scatter `cursor` is free: it becomes the list of heavy buckets, counts[nb] their number
-__global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1J* __restrict__ partial,
-                                                uint32_t* __restrict__ heavy, G1J* __restrict__ bucket_pts, uint32_t nb) {
+__global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
+                                                uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t cnt = counts[b], off = offsets[b];
@@ -416,8 +425,8 @@ __global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, c
     for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off));
     bucket_pts[b] = acc;
 }
-__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1J* __restrict__ partial,
-                                                                     const uint32_t* __restrict__ heavy, G1J* __restrict__ bucket_pts, uint32_t nb) {
+__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
+                                                                     const uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
     __shared__ G1J red[MSM_HEAVY_THREADS];
     const uint32_t n_heavy = counts[nb];
     const uint32_t t = threadIdx.x;
@@ -440,7 +449,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
 }
 
 // complete formulas for the rare window slice in which a running sum meets an equal or opposite point
-__device__ __noinline__ void msm_slice_slow(const G1J* __restrict__ bp, uint32_t lo, uint32_t hi, uint32_t c, G1J* __restrict__ out) {
+__device__ __noinline__ void msm_slice_slow(const G1JSlot* __restrict__ bp, uint32_t lo, uint32_t hi, uint32_t c, G1J* __restrict__ out) {
     G1J run = G1J::identity(), sum = G1J::identity();
     for (uint32_t b = hi; b > lo; --b) { run = g1_add(run, bp[b - 1]); sum = g1_add(sum, run); }
     if (lo < hi && lo > 0) {
@@ -451,13 +460,13 @@ __device__ __noinline__ void msm_slice_slow(const G1J* __restrict__ bp, uint32_t
     *out = sum;
 }
 
-__global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restrict__ bucket_pts, G1J* __restrict__ window_sums, MsmPlan p) {
+__global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ window_sums, MsmPlan p) {
     __shared__ G1J red[MSM_WIN_THREADS];
     const uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x, T = blockDim.x;   // T: a power of two (msm_window_threads)
     const uint32_t slice = (p.buckets + T - 1) / T;
     const uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
     G1J run = G1J::identity(), sum = G1J::identity();
-    const G1J* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
+    const G1JSlot* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
     bool ok = true;
     for (uint32_t b = hi; b > lo && ok; --b) {
         ok = g1_add_fast(run, bp[b - 1]);
@@ -482,7 +491,7 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1J* __restr
     if (t == 0) window_sums[(size_t)q * p.windows + w] = red[0];
 }
 
-__global__ void __launch_bounds__(64) msm_final(const G1J* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p) {
+__global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= count) return;
     G1J acc = G1J::identity();
@@ -524,19 +533,20 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     uint32_t nbq = p.windows * p.buckets, nb = nbq * count;
     if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 2) * 4, s));
-    dim3 gt((nmax + MSM_TILE - 1) / MSM_TILE, count);
+    const uint32_t tiles = (nmax + MSM_TILE - 1) / MSM_TILE;
+    dim3 gt(8 * ((count + 7) / 8) * tiles);
     const uint32_t wpp = std::max<uint32_t>(1u, std::min<uint32_t>(p.windows, MSM_LDS_WORDS / p.buckets));
     const size_t lds = (size_t)wpp * p.buckets * 4;
-    hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
+    hipLaunchKernelGGL(msm_count_or_scatter<false>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, count, tiles, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
     const uint32_t nblk = (nb + 1023) / 1024;
     hipLaunchKernelGGL(msm_block_sums, dim3(nblk), dim3(1024), 0, s, ws.counts, ws.block_sums, nb);
     hipLaunchKernelGGL(msm_scan_sums, dim3(1), dim3(1024), 0, s, ws.block_sums, nblk, ws.counts + nb + 1);
     hipLaunchKernelGGL(msm_offsets, dim3(nblk), dim3(1024), 0, s, ws.counts, ws.block_sums, ws.offsets, ws.cursor, nb);
-    hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
+    hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, count, tiles, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
     // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers its upper bound
     const size_t max_entries = total * 2 * p.windows;
     const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK - 1) / MSM_CHUNK);
-    hipLaunchKernelGGL(msm_accumulate, dim3((chunks + 63) / 64), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
+    hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(msm_window_threads(p.buckets)), 0, s, ws.bucket_pts, ws.window_sums, p);
