@@ -98,3 +98,51 @@ def test_full_size_batch_properties(big):
     e2 = ctx.verify_batch(P[:64], I[:64], None)
     assert e1[0] and e2[0] and (e1[2], e1[3]) != (e2[2], e2[3])
     ctx.close()
+
+
+def test_config3_shard_size(big):
+    """BASELINE.json config 3 gives every GPU 8192 proofs (65 536 over 8).  At that size (the 1024 distinct proofs cycled):
+    one batch == the fold of 8 shards of 1024 with the draw tails of their global positions; the same bytes as one grouped
+    launch == 8 independent 1024-proof batches; and a single bad proof anywhere rejects the whole batch."""
+    import torch
+    import halo2_verifier_amd as h2v
+    from halo2_verifier_amd import distributed as h2d
+    s, P, I = big
+    ctx = _ctx(s)
+    n = 8192
+    PP, II = (P * 8)[:n], (I * 8)[:n]
+    rnd = random.Random(4242)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    rand_all = b"".join(r.to_bytes(32, "little") for r in rand)
+    flat = b"".join(PP)
+    inst = b"".join(b"".join(col) for i in II for col in i)
+    b = h2v.Batch(ctx, n, 8)
+    b.upload(flat, 1024, inst, [8], rand_all)
+    b.launch()
+    whole = b.finish()
+    b.close()
+    assert whole[0] is True and whole[1] == [0] * n
+    assert _sharded(ctx, PP, II, rand, 8) == whole
+    # the same bytes as ONE grouped launch: 8 independent batches
+    g = h2v.Batch(ctx, n, 8, groups=8)
+    # (as independent batches: a group's multipliers stop at the end of its own 1024 proofs)
+    g.upload(flat, 1024, inst, [8], rand_all)
+    g.launch()
+    oks, st, lefts, rights = g.finish_groups()
+    g.close()
+    assert oks == [True] * 8 and st == [0] * n
+    for r in (0, 3, 7):
+        sl = slice(1024 * r, 1024 * (r + 1))
+        ref = ctx.verify_batch(PP[sl], II[sl], rand[sl])
+        assert (oks[r], lefts[r], rights[r]) == (ref[0], ref[2], ref[3])
+    # one tampered public input at position 5000
+    I2 = list(II)
+    I2[5000] = [[circuits.le32(7)] + II[5000][0][1:]]
+    inst2 = b"".join(b"".join(col) for i in I2 for col in i)
+    b = h2v.Batch(ctx, n, 8)
+    b.upload(flat, 1024, inst2, [8], rand_all)
+    b.launch()
+    bad = b.finish()
+    b.close()
+    assert bad[0] is False and bad[1] == [0] * n
+    ctx.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ad-hoc measurement of BASELINE.json config 4 (lookup-heavy VK: 32 advice, 16 fixed, 8 two-column lookups, degree 5):
-batches of `--batch` proofs, `--depth` in flight.  Not the headline bench (bench.py); numbers quoted in DESIGN.md."""
+batches of `--batch` proofs, `--groups` batches per launch, `--depth` launches in flight.  Not the headline bench (bench.py); numbers quoted in DESIGN.md."""
 import argparse, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,8 @@ import halo2_verifier_amd as h2v
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
-ap.add_argument("--depth", type=int, default=16)
+ap.add_argument("--depth", type=int, default=8)
+ap.add_argument("--groups", type=int, default=8)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--distinct", type=int, default=32)
 ap.add_argument("--k", type=int, default=10)
@@ -22,24 +23,25 @@ for i in range(a.distinct):
     P.append(p); I.append(inst)
 plen = len(P[0])
 reps = (a.batch + a.distinct - 1) // a.distinct
-pf = (b"".join(P) * reps)[: a.batch * plen]
-inf = (b"".join(b"".join(c) for i in I for c in i) * reps)[: a.batch * 8 * 32]
+G = a.groups
+pf = (b"".join(P) * reps)[: a.batch * plen] * G
+inf = (b"".join(b"".join(c) for i in I for c in i) * reps)[: a.batch * 8 * 32] * G
 ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
 print("shape", ctx.proof_shape())
-tail = b"".join(((i * 0x9e3779b97f4a7c15 + 77) % (1 << 250)).to_bytes(32, "little") for i in range(1, a.batch + 1))
+tail = b"".join(((i * 0x9e3779b97f4a7c15 + 77) % (1 << 250)).to_bytes(32, "little") for i in range(1, a.batch * G + 1))
 bs = []
 for _ in range(a.depth):
-    b = h2v.Batch(ctx, a.batch, 8); b.upload(pf, plen, inf, [8], tail); b.set_profiling(True); bs.append(b)
+    b = h2v.Batch(ctx, a.batch * G, 8, groups=G); b.upload(pf, plen, inf, [8], tail); b.set_profiling(True); bs.append(b)
 fl = [False] * a.depth
 def run(n):
     for st in range(n):
         i = st % a.depth
         if fl[i]:
-            ok, stt, _, _ = bs[i].finish(); assert ok and not any(stt)
+            ok, stt, _, _ = bs[i].finish_groups(); assert all(ok) and not any(stt)
         bs[i].launch(True); fl[i] = True
     for i in range(a.depth):
         if fl[i]:
-            ok, stt, _, _ = bs[i].finish(); assert ok and not any(stt); fl[i] = False
+            ok, stt, _, _ = bs[i].finish_groups(); assert all(ok) and not any(stt); fl[i] = False
 run(a.depth)
 t = time.perf_counter(); run(a.steps); dt = time.perf_counter() - t
-print(f"config4-shape VK: batch {a.batch}, depth {a.depth}: {a.batch * a.steps / dt:.0f} proofs/s, {dt / a.steps * 1e3:.2f} ms/step, proof {plen} B, stages {bs[0].timings_ms()}")
+print(f"config4-shape VK: batch {a.batch} x {G} groups per launch, depth {a.depth}: {a.batch * G * a.steps / dt:.0f} proofs/s, {dt / a.steps / G * 1e3:.3f} ms per {a.batch}-proof batch, proof {plen} B, stages {bs[0].timings_ms()}")
