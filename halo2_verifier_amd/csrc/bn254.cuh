@@ -232,6 +232,34 @@ template <class PR> struct Fp {
         r.v[8] = (uint32_t)acc;
         return r;
     }
+    // (a0*b0 + a1*b1)/R mod p in ONE reduction pass: 27 terms per column still fit the 64-bit accumulator (27 * 2^58 + carry
+    // < 2^63).  Representatives < 2p give a result < 1.05p.  This is what makes an Fq2 product two passes and no additions.
+    __host__ __device__ __forceinline__ static Fp dot2_inl(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1) {
+        uint64_t acc = 0;
+        uint32_t m[9];
+        Fp r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) { acc += (uint64_t)a0.v[i] * b0.v[k - i]; acc += (uint64_t)a1.v[i] * b1.v[k - i]; }
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * PR::P29(k - i);
+            m[k] = ((uint32_t)acc * PR::INV29) & H2V_LIMB_MASK;
+            acc += (uint64_t)m[k] * PR::P29(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; ++i) { acc += (uint64_t)a0.v[i] * b0.v[k - i]; acc += (uint64_t)a1.v[i] * b1.v[k - i]; }
+#pragma unroll
+            for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * PR::P29(k - i);
+            r.v[k - 9] = (uint32_t)acc & H2V_LIMB_MASK;
+            acc >>= 29;
+        }
+        r.v[8] = (uint32_t)acc;
+        return r;
+    }
     // a^2/R mod p: the 36 off-diagonal products are taken once against doubled limbs (45 + 81 multiply-adds instead of 162)
     __host__ __device__ __forceinline__ Fp sqr_inl() const {
         uint64_t acc = 0;

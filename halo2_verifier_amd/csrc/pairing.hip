@@ -31,19 +31,90 @@ struct WaveShared {
     Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6];
 };
 
-// dst = x * y in Fq2[w]/(w^6 - xi); dst may alias x or y
-__device__ __forceinline__ void wmul(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {
-    if (lane < 36) s.prod[lane] = Fq2::mul(x[lane / 6], y[lane % 6]);
-    __syncthreads();
-    if (lane < 6) {
-        Fq2 lo = Fq2::zero(), hi = Fq2::zero();
-        for (uint32_t i = 0; i < 6; ++i) {
-            if (i <= lane) lo = lo + s.prod[i * 6 + (lane - i)];
-            else hi = hi + s.prod[i * 6 + (lane + 6 - i)];
+// Fq2 product as two sum-of-two-products passes (no Karatsuba additions): c0 = a0*b0 + a1*(-b1), c1 = a0*b1 + a1*b0.
+// Results are < 1.05p each.
+__device__ __noinline__ Fq2 fq2_mul_dot(Fq2 a, Fq2 b) {
+    const Fq nb1 = b.c1.neg();
+    return {Fq::dot2_inl(a.c0, b.c0, a.c1, nb1), Fq::dot2_inl(a.c0, b.c1, a.c1, b.c0)};
+}
+// One Fq coordinate (c = 0: real, 1: imaginary) of coefficient k of  sum_{i+j=k} P_ij + xi * sum_{i+j=k+6} P_ij,  xi = 9 + u,
+// from the 36 partial products: an INTEGER linear combination of up to 11 residues with weights 1, 9 and -1 (as 2p - x),
+// accumulated per limb in 64 bits, carried once, and brought back below 2p by one Montgomery pass with R mod p (the
+// combination is < 64p; a product with a factor < p divides it by R again: < 1.4p).  Replaces ~36 modular additions.
+__device__ __noinline__ Fq wfold_coord(const Fq2* __restrict__ prod, uint32_t k, uint32_t c) {
+    // 32-bit per-limb sums first (six residues of 29-bit limbs cannot overflow): SL = the lo terms' coordinate, SH = the hi
+    // terms' coordinate, OH = the hi terms' other coordinate
+    uint32_t SL[9], SH[9], OH[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) { SL[l] = 0; SH[l] = 0; OH[l] = 0; }
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+        const bool lo = i <= k;
+        const Fq2& P = prod[i * 6 + (lo ? k - i : k + 6 - i)];
+        const Fq& same = c ? P.c1 : P.c0;
+        const Fq& other = c ? P.c0 : P.c1;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            const uint32_t x = same.v[l], y = other.v[l];
+            SL[l] += lo ? x : 0u;
+            SH[l] += lo ? 0u : x;
+            OH[l] += lo ? 0u : y;
         }
-        dst[lane] = lo + hi.mul_xi();
+    }
+    // SL + 9 SH + OH (imaginary) or SL + 9 SH + (n_hi * 2p - OH) (real), carried once
+    const int64_t n_hi = 5 - (int64_t)k;
+    Fq v;
+    int64_t carry = 0;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+        int64_t t = (int64_t)SL[l] + (((int64_t)SH[l]) << 3) + (int64_t)SH[l] + carry;
+        t += c ? (int64_t)OH[l] : n_hi * (int64_t)(2u * FqParams::P29(l)) - (int64_t)OH[l];
+        if (l < 8) { v.v[l] = (uint32_t)(t & (int64_t)H2V_LIMB_MASK); carry = t >> 29; } else v.v[l] = (uint32_t)t;   // total < 64p < 2^261
+    }
+    return Fq::mul_inl(v, Fq::one());
+}
+
+// one coordinate of an Fq2 product, one reduction pass: real = a0*b0 + a1*(-b1), imaginary = a0*b1 + a1*b0 (< 1.05p)
+__device__ __noinline__ Fq fq2_mul_coord(Fq2 a, Fq2 b, uint32_t coord) {
+    const Fq s0 = coord ? b.c1 : b.c0, s1 = coord ? b.c0 : b.c1.neg();
+    return Fq::dot2_inl(a.c0, s0, a.c1, s1);
+}
+__device__ __forceinline__ void prod_store(Fq2* prod, uint32_t idx, uint32_t coord, const Fq& v) { if (coord) prod[idx].c1 = v; else prod[idx].c0 = v; }
+__device__ __forceinline__ void wfold(WaveShared& s, Fq2* dst, uint32_t lane) {
+    __syncthreads();
+    if (lane < 12) {
+        const Fq r = wfold_coord(s.prod, lane >> 1, lane & 1);
+        if (lane & 1) dst[lane >> 1].c1 = r; else dst[lane >> 1].c0 = r;
     }
     __syncthreads();
+}
+// dst = x * y in Fq2[w]/(w^6 - xi); dst may alias x or y.  36 lanes, two passes each.
+__device__ __forceinline__ void wmul(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {
+    if (lane < 36) s.prod[lane] = fq2_mul_dot(x[lane / 6], y[lane % 6]);
+    wfold(s, dst, lane);
+}
+// dst = x^2: the 21 products a_i*a_j, i <= j, are each computed once — 42 lanes, ONE pass each — and stored at both (i, j) and (j, i)
+__device__ __forceinline__ void wsqr(WaveShared& s, Fq2* dst, const Fq2* x, uint32_t lane) {
+    if (lane < 42) {
+        const uint32_t pr = lane >> 1, coord = lane & 1;
+        // pair number -> (i, j), i <= j, rows of lengths 6, 5, 4, 3, 2, 1
+        uint32_t i = 0, r = pr;
+        while (r >= 6 - i) { r -= 6 - i; ++i; }
+        const uint32_t j = i + r;
+        const Fq v = fq2_mul_coord(x[i], x[j], coord);
+        prod_store(s.prod, i * 6 + j, coord, v);
+        prod_store(s.prod, j * 6 + i, coord, v);
+    }
+    wfold(s, dst, lane);
+}
+// dst = x * l for a line product l (coefficient of w^5 is zero): 30 Fq2 products, 60 lanes, ONE pass each
+__device__ __forceinline__ void wmul_line(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* l, uint32_t lane) {
+    if (lane < 60) {
+        const uint32_t pr = lane >> 1, coord = lane & 1, i = pr / 5, j = pr % 5;
+        prod_store(s.prod, i * 6 + j, coord, fq2_mul_coord(x[i], l[j], coord));
+    }
+    if (lane < 12) prod_store(s.prod, (lane >> 1) * 6 + 5, lane & 1, Fq::zero());
+    wfold(s, dst, lane);
 }
 __device__ __forceinline__ void wcopy(Fq2* dst, const Fq2* src, uint32_t lane) { if (lane < 6) dst[lane] = src[lane]; __syncthreads(); }
 // x -> x^(p^6): w -> -w
@@ -64,7 +135,7 @@ __device__ __noinline__ void winv_lane0(Fq2* dst, const Fq2* src) {
 __device__ __forceinline__ void wpow_x(WaveShared& s, Fq2* dst, const Fq2* x, uint32_t lane) {
     wcopy(dst, x, lane);
     for (int i = 61; i >= 0; --i) {
-        wmul(s, dst, dst, dst, lane);
+        wsqr(s, dst, dst, lane);
         if ((BN_X >> i) & 1) wmul(s, dst, dst, x, lane);
     }
 }
@@ -105,12 +176,12 @@ __global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pai
     // Miller loop: one squaring and one product per doubling step, one more product per addition step
     uint32_t idx = 0;
     for (int i = 63; i >= 0; --i) {
-        wmul(s, s.f, s.f, s.f, lane);
-        wmul(s, s.f, s.f, s.line[idx++], lane);
-        if ((ATE_LOW >> i) & 1) wmul(s, s.f, s.f, s.line[idx++], lane);
+        wsqr(s, s.f, s.f, lane);
+        wmul_line(s, s.f, s.f, s.line[idx++], lane);
+        if ((ATE_LOW >> i) & 1) wmul_line(s, s.f, s.f, s.line[idx++], lane);
     }
-    wmul(s, s.f, s.f, s.line[idx++], lane);
-    wmul(s, s.f, s.f, s.line[idx++], lane);
+    wmul_line(s, s.f, s.f, s.line[idx++], lane);
+    wmul_line(s, s.f, s.f, s.line[idx++], lane);
     // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
     if (lane == 0) winv_lane0(s.t0, s.f);
     __syncthreads();
@@ -122,11 +193,11 @@ __global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pai
     // hard part: the x-power chain of Fuentes-Castaneda et al. (y0 .. y16)
     Fq2 *y0 = s.t0, *y1 = s.t1, *y3 = s.t2, *y4 = s.t3, *y6 = s.t4, *u = s.t5, *v = s.t6;
     wpow_x(s, y0, s.r, lane); wconj(y0, y0, lane);               // y0 = r^-x
-    wmul(s, y1, y0, y0, lane);                                   // y1 = y0^2
-    wmul(s, u, y1, y1, lane);                                    // y2 = y1^2
+    wsqr(s, y1, y0, lane);                                       // y1 = y0^2
+    wsqr(s, u, y1, lane);                                        // y2 = y1^2
     wmul(s, y3, u, y1, lane);                                    // y3 = y2 * y1
     wpow_x(s, y4, y3, lane); wconj(y4, y4, lane);                // y4 = y3^-x
-    wmul(s, u, y4, y4, lane);                                    // y5 = y4^2
+    wsqr(s, u, y4, lane);                                        // y5 = y4^2
     wpow_x(s, y6, u, lane); wconj(y6, y6, lane);                 // y6 = y5^-x
     wconj(y3, y3, lane);
     wconj(y6, y6, lane);
