@@ -448,18 +448,10 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
     }
 }
 
-// complete formulas for the rare window slice in which a running sum meets an equal or opposite point
-__device__ __noinline__ void msm_slice_slow(const G1JSlot* __restrict__ bp, uint32_t lo, uint32_t hi, uint32_t c, G1J* __restrict__ out) {
-    G1J run = G1J::identity(), sum = G1J::identity();
-    for (uint32_t b = hi; b > lo; --b) { run = g1_add(run, bp[b - 1]); sum = g1_add(sum, run); }
-    if (lo < hi && lo > 0) {
-        G1J scaled = G1J::identity();
-        for (int i = (int)c - 1; i >= 0; --i) { scaled = g1_dbl(scaled); if ((lo >> i) & 1) scaled = g1_add(scaled, run); }
-        sum = g1_add(sum, scaled);
-    }
-    *out = sum;
-}
-
+// A lone wave per window is latency-bound, and the two inlined additions of the running-sum step are ~70 KB of code —
+// more than the instruction cache, so every iteration streamed its code from L2 (measured 2x the time of the arithmetic).
+// Here the group law is the shared out-of-line routine (one 35 KB body, complete formulas): the accumulators live in
+// memory across the calls, which costs a 108-byte load/store against a ~9 us addition.
 __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ window_sums, MsmPlan p) {
     __shared__ G1J red[MSM_WIN_THREADS];
     const uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x, T = blockDim.x;   // T: a power of two (msm_window_threads)
@@ -467,22 +459,20 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
     const uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
     G1J run = G1J::identity(), sum = G1J::identity();
     const G1JSlot* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
-    bool ok = true;
-    for (uint32_t b = hi; b > lo && ok; --b) {
-        ok = g1_add_fast(run, bp[b - 1]);
-        if (ok) ok = g1_add_fast(sum, run);
+    for (uint32_t b = hi; b > lo; --b) {
+        run = g1_add(run, bp[b - 1]);
+        sum = g1_add(sum, run);
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
-    if (ok && lo < hi && lo > 0) {
+    if (lo < hi && lo > 0) {
         G1J scaled = G1J::identity();
-        for (int i = (int)p.c - 1; i >= 0 && ok; --i) {
-            scaled = g1_dbl_inl(scaled);
-            if ((lo >> i) & 1) ok = g1_add_fast(scaled, run);
+        for (int i = (int)p.c - 1; i >= 0; --i) {
+            scaled = g1_dbl(scaled);
+            if ((lo >> i) & 1) scaled = g1_add(scaled, run);
         }
-        if (ok) ok = g1_add_fast(sum, scaled);
+        sum = g1_add(sum, scaled);
     }
-    if (ok) red[t] = sum;
-    else msm_slice_slow(bp, lo, hi, p.c, &red[t]);  // degenerate meeting of equal / opposite points: complete formulas
+    red[t] = sum;
     __syncthreads();
     for (uint32_t d = T / 2; d > 0; d >>= 1) {
         if (t < d) red[t] = g1_add(red[t], red[t + d]);
@@ -497,7 +487,7 @@ __global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ wind
     G1J acc = G1J::identity();
     if (prs[q].n) {
         for (int w = (int)p.windows - 1; w >= 0; --w) {
-            for (uint32_t i = 0; i < p.c; ++i) acc = g1_dbl_inl(acc);
+            for (uint32_t i = 0; i < p.c; ++i) acc = g1_dbl(acc);
             acc = g1_add(acc, window_sums[(size_t)q * p.windows + w]);
         }
     }
