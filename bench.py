@@ -82,10 +82,10 @@ def cpu_baseline(d, sample, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--groups", type=int, default=16, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups)")
+    ap.add_argument("--groups", type=int, default=32, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups)")
     ap.add_argument("--depth", type=int, default=8, help="launches in flight per GPU (one HIP stream each)")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
     ap.add_argument("--cpu-sample", type=int, default=2048)

@@ -19,7 +19,7 @@ void set_last_error(const std::string& s);
     } while (0)
 
 // ------------------------------------------------------------------ MSM (msm.hip)
-// Pippenger over pooled (scalar, base) terms.  Scalars: canonical little-endian limbs, 8 x u32 per
+// Pippenger over pooled (scalar, base) terms.  Scalars: canonical little-endian 32-bit words, 8 per
 // term; bases: affine Montgomery, (0,0) = identity (skipped).
 struct MsmPlan {
     uint32_t n;        // terms
@@ -77,7 +77,7 @@ int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, cons
 // ------------------------------------------------------------------ small helpers (util.hip)
 // canonical x|y bytes (64 B each, all-zero = identity) -> affine Montgomery; flags[i] = 0 ok, 1 not canonical / not on curve
 int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, uint32_t* d_flags, uint32_t n);
-// canonical 32-B scalars -> 8 x u32 limbs (validated < r); flags[i] = 1 when >= r
+// canonical 32-B scalars -> 8 x 32-bit words (validated < r); flags[i] = 1 when >= r
 int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
 // Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n);

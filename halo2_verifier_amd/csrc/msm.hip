@@ -33,10 +33,10 @@
 // atomics are 32-bit counters.  The order of additions inside a bucket depends on atomic
 // arrival order, but the group element — hence the affine bytes — does not.
 //
-// Arithmetic intensity: one term = 96 B read (32 B scalar + 64 B affine base) and `windows`
-// mixed additions (~11 Fq multiplications each, ~128 v_mad_u64_u32 per multiplication), i.e.
-// O(10^4-10^5) integer ops per 96 bytes: the kernel is bound by 32-bit integer multiply issue,
-// not by HBM (DESIGN.md "Roofline").
+// Arithmetic intensity: one term = 96 algorithmic bytes (32 B canonical scalar + 64 B canonical affine base; in memory
+// 32 B of scalar words + a 72 B affine point in 29-bit limbs) and 2 * windows mixed additions (7 Fq products + 4 squarings
+// each, ~162 v_mad_u64_u32 per product), i.e. ~6 * 10^4 integer instructions per 96 bytes: the stage is bound by
+// 32-bit integer multiply issue, not by HBM (DESIGN.md "Roofline").
 #include "../../include/h2v.h"
 #include "batch.h"
 
@@ -361,7 +361,7 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
         }
     }
 }
-__global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(64, 3) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb) {
     const uint32_t E = counts[nb + 1];
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
