@@ -128,35 +128,38 @@ def main():
     # A step is one batch of B proofs per GPU with its own accumulators and its own pairing (AccumulatorStrategy).  One launch
     # carries G steps side by side (a grouped batch): every kernel runs once for all G, each group keeps its own verdict.
     B = args.batch
-    G = math.gcd(max(1, args.groups), args.steps)   # exactly --steps timed steps
-    launches = args.steps // G
+    # EXACTLY --steps timed steps: `launches` launches of G steps, plus one launch of the remaining `rem` steps (own object)
+    G = max(1, min(args.groups, args.steps))
+    launches, rem = args.steps // G, args.steps % G
     warm_launches = (args.warmup + G - 1) // G
     reps = (B + args.distinct - 1) // args.distinct
-    proofs_flat = (d["proofs"] * reps)[: B * 1024] * G
-    inst_flat = (d["inst"] * reps)[: B * 32 * N_PUBLIC] * G
+    proofs_one = (d["proofs"] * reps)[: B * 1024]
+    inst_one = (d["inst"] * reps)[: B * 32 * N_PUBLIC]
     total = B * world
     lo, hi = h2d.shard_bounds(total, world, rank)
     # per group one seeded stream of Fr::random draws for the whole (N x batch) step, indexed by global proof id; a rank
     # uploads, for every group, the draws from its first proof to the end of the step (the multiplier of a proof is the
     # product of the draws of all later proofs of its step)
-    tail = b""
+    tails = []
     for g in range(G):
         rand_all = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567 + g * 0x51ed27) % (1 << 250)).to_bytes(32, "little") for i in range(1, total + 1))
-        tail += h2d.tail_for_shard(rand_all, lo)
+        tails.append(h2d.tail_for_shard(rand_all, lo))
 
     ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes), device=local_rank)
     shape = ctx.proof_shape()
     depth = max(1, min(args.depth, launches))
-    streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)]
+    # objects 0 .. depth-1 carry G steps each; object `depth` (if any) carries the `rem` steps that complete --steps
+    sizes = [G] * depth + ([rem] if rem else [])
+    streams = [torch.cuda.Stream(device=local_rank) for _ in sizes]
     batches = []
-    for s in streams:
-        b = h2v.Batch(ctx, B * G, N_PUBLIC, stream=s.cuda_stream, groups=G)
-        b.upload(proofs_flat, 1024, inst_flat, [N_PUBLIC], tail)   # resident in HBM before the timed region
+    for s, g in zip(streams, sizes):
+        b = h2v.Batch(ctx, B * g, N_PUBLIC, stream=s.cuda_stream, groups=g)
+        b.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
         b.set_profiling(True)
         batches.append(b)
-    acc_local = [torch.empty(h2d.ACC_BYTES * G, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(depth)]
-    gathered = [None] * depth
-    in_flight = [False] * depth
+    acc_local = [torch.empty(h2d.ACC_BYTES * g, dtype=torch.uint8, device=f"cuda:{local_rank}") for g in sizes]
+    gathered = [None] * len(sizes)
+    in_flight = [False] * len(sizes)
     stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
     stage_cnt = 0
     results = []
@@ -167,7 +170,7 @@ def main():
         in_flight[i] = False
         if not all(ok) or any(st):
             raise SystemExit(f"verification failed inside the benchmark: ok={ok}")
-        if timed:
+        if timed and i < depth:   # stage statistics are per full launch
             for k2, v in batches[i].timings_ms().items():
                 stage_sum[k2] += v
             stage_cnt += 1
@@ -185,13 +188,15 @@ def main():
                 b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
         in_flight[i] = True
 
-    def run(nsteps, timed):
-        for step in range(nsteps):
+    def run(n_launches, timed):
+        for step in range(n_launches):
             i = step % depth
             if in_flight[i]:
                 retire(i, timed)
             submit(i)
-        for i in range(depth):
+        if rem:
+            submit(depth)
+        for i in range(len(sizes)):
             if in_flight[i]:
                 retire(i, timed)
 

@@ -11,7 +11,7 @@ set -e
 OUT="$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-D1="--steps 64 --warmup 16 --depth 1 --no-cpu-baseline"
+D1="--steps 128 --warmup 32 --depth 1 --no-cpu-baseline"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/default" -o k --output-format csv -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$OUT/default.json" 2> "$OUT/default.err"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/depth1" -o k --output-format csv -- python3 "$GRAFT_REPO_ROOT/bench.py" $D1 > "$OUT/depth1.json" 2> "$OUT/depth1.err"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o k --output-format csv -- python3 "$GRAFT_REPO_ROOT/bench.py" $D1 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"

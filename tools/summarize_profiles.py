@@ -45,8 +45,8 @@ stats("default", f"{tag}_kernel_stats_default_cmd.csv",
        "%s" % bd.get("config", {}).get("workload", ""),
        "bench line of this run: value=%.0f proofs/s, ms_per_step=%.4f (kernels of different launches overlap, durations are inflated by sharing)" % (bd.get("value", 0), bd.get("ms_per_step", 0))])
 avg1 = stats("depth1", f"{tag}_kernel_stats_depth1.csv",
-             ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 64 --warmup 16 --depth 1 --no-cpu-baseline",
-              "one launch in flight (16 steps = 16 x 1024 proofs per launch), so per-kernel durations are undisturbed",
+             ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 128 --warmup 32 --depth 1 --no-cpu-baseline",
+              "one launch in flight (32 steps = 32 x 1024 proofs per launch), so per-kernel durations are undisturbed",
               "bench line of this run: value=%.0f proofs/s, stages_ms=%s" % (b1.get("value", 0), json.dumps(b1.get("stages_ms", {})))])
 
 
@@ -60,7 +60,7 @@ def counters(sub):
 
 fetch, write, valu = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_valu")
 with open(os.path.join(out, f"{tag}_pmc_fetch_write.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE -- python3 bench.py --steps 64 --warmup 16 --depth 1 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE -- python3 bench.py --steps 128 --warmup 32 --depth 1 --no-cpu-baseline\n")
     f.write("# mean counter value per dispatch; unit KB (bytes = value * 1024); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM)\n")
     f.write("Kernel,Counter,Dispatches,MeanValueKB\n")
     for d in (fetch, write):
@@ -68,7 +68,7 @@ with open(os.path.join(out, f"{tag}_pmc_fetch_write.csv"), "w") as f:
             if k.startswith("h2v::"):
                 f.write('"%s",%s,%d,%.1f\n' % (k, c, n, v))
 with open(os.path.join(out, f"{tag}_pmc_valu.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY -- python3 bench.py --steps 64 --warmup 16 --depth 1 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY -- python3 bench.py --steps 128 --warmup 32 --depth 1 --no-cpu-baseline\n")
     f.write("# mean per dispatch; SQ_* cycle counters are in quad-cycles; valu_active = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of wave time spent issuing VALU)\n")
     f.write("Kernel,Dispatches,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_ACTIVE_INST_VALU,SQ_INSTS_VALU,SQ_WAIT_INST_ANY,valu_active\n")
     ks = sorted({k for (k, c) in valu if k.startswith("h2v::")}, key=lambda k: -valu.get((k, "SQ_WAVE_CYCLES"), (0, 0))[0])
