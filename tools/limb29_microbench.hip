@@ -1,5 +1,8 @@
-// Prototype + micro-benchmark: Fq Montgomery product with 9 x 29-bit limbs (product scanning, 64-bit column
-// accumulators, no carry chains) against the 8 x 32-bit CIOS product of bn254.cuh, on gfx950.
+// Micro-benchmark of the Fq Montgomery product with 9 x 29-bit limbs (product scanning, 64-bit column accumulators, no carry
+// chains) on gfx950: the prototype this file started as (mul29 / sqr29 / add29, kept here), the library's own Fq::mul_inl
+// (csrc/bn254.cuh adopted the prototype; the 8 x 32-bit CIOS product it replaced measured 1052 ns on a lone wave and
+// 83 G products/s chip-wide with this same harness), a two-accumulator variant (no gain: recorded negative result), and the
+// product rate as a function of occupancy (1, 2, 3 waves per SIMD) — the MSM kernels run at 2 waves per SIMD.
 // Build: hipcc -O3 --offload-arch=gfx950 -I halo2_verifier_amd/csrc tools/limb29_microbench.hip -o tools/limb29_microbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,6 +43,37 @@ __device__ __forceinline__ F29 mul29(const F29& a, const F29& b) {
         for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
 #pragma unroll
         for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * p29(k - i);
+        r.v[k - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+// two accumulators per column (a*b terms / m*p terms): halves the dependent v_mad_u64_u32 chain of a lone wave
+__device__ __forceinline__ F29 mul29_2acc(const F29& a, const F29& b) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        uint64_t acc2 = 0;
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc2 += (uint64_t)m[i] * p29(k - i);
+        acc += acc2;
+        m[k] = ((uint32_t)acc * INV29) & MASK29;
+        acc += (uint64_t)m[k] * p29(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+        uint64_t acc2 = 0;
+#pragma unroll
+        for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; ++i) acc2 += (uint64_t)m[i] * p29(k - i);
+        acc += acc2;
         r.v[k - 9] = (uint32_t)acc & MASK29;
         acc >>= 29;
     }
@@ -113,6 +147,12 @@ __global__ void k29_chain(F29* io, int iters) {
     for (int k = 0; k < iters; ++k) a = mul29(a, b);
     io[i] = a;
 }
+__global__ void k29_chain_2acc(F29* io, int iters) {
+    size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    F29 a = io[i], b = a;
+    for (int k = 0; k < iters; ++k) a = mul29_2acc(a, b);
+    io[i] = a;
+}
 __global__ void k29_chain_sqr(F29* io, int iters) {
     size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
     F29 a = io[i];
@@ -177,7 +217,7 @@ int main() {
         run(k32_chain, d32, 1, 64, it);
         Fq h; hipMemcpy(&h, d32, sizeof(Fq), hipMemcpyDeviceToHost);
         uint32_t r32[8]; h.to_raw(r32);
-        printf("iters=%d limb32 result words (lsb first):", it);
+        printf("iters=%d library result words (lsb first):", it);
         for (int j = 0; j < 8; ++j) printf(" %08x", r32[j]);
         printf("\n");
         (void)lo; (void)hi;
@@ -185,23 +225,33 @@ int main() {
     const int it = 2000;
     reset();
     printf("one wave, dependent chain (ns per op):\n");
-    printf("  mul 8x32 %8.1f\n", run(k32_chain, d32, 1, 64, it) * 1e6 / it);
+    printf("  library Fq::mul_inl %8.1f\n", run(k32_chain, d32, 1, 64, it) * 1e6 / it);
     printf("  mul 9x29 %8.1f\n", run(k29_chain, d29, 1, 64, it) * 1e6 / it);
+    printf("  mul 9x29 2 accumulators %8.1f\n", run(k29_chain_2acc, d29, 1, 64, it) * 1e6 / it);
     printf("  sqr 9x29 %8.1f\n", run(k29_chain_sqr, d29, 1, 64, it) * 1e6 / it);
     printf("  mul 9x29 x4 %8.1f (per mul)\n", run(k29_chain4, d29, 1, 64, it) * 1e6 / it / 4);
-    printf("  add 8x32 %8.1f\n", run(k32_chain_add, d32, 1, 64, it) * 1e6 / it / 2);
+    printf("  library Fq add %8.1f\n", run(k32_chain_add, d32, 1, 64, it) * 1e6 / it / 2);
     printf("  add 9x29 %8.1f\n", run(k29_chain_add, d29, 1, 64, it) * 1e6 / it / 2);
+    printf("low occupancy (1024 blocks x 64 threads = 1 wave per SIMD; 2048 = 2), G mul/s:\n");
+    for (int blocks : {1024, 2048, 3072}) {
+        reset();
+        float ms1 = run(k29_chain, d29, blocks, 64, it);
+        reset();
+        float ms2 = run(k29_chain_2acc, d29, blocks, 64, it);
+        printf("  blocks=%5d  1 acc %8.2f   2 acc %8.2f\n", blocks, (double)blocks * 64 * it / ms1 / 1e6, (double)blocks * 64 * it / ms2 / 1e6);
+    }
     printf("full chip, G op/s:\n");
     for (int blocks : {1024, 4096}) {
         reset();
+        { float ms2 = run(k29_chain_2acc, d29, blocks, 256, it); printf("  mul 9x29 2acc blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it / ms2 / 1e6); reset(); }
         float ms = run(k32_chain, d32, blocks, 256, it);
-        printf("  mul 8x32 blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it / ms / 1e6);
+        printf("  library mul blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it / ms / 1e6);
         ms = run(k29_chain, d29, blocks, 256, it);
         printf("  mul 9x29 blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it / ms / 1e6);
         ms = run(k29_chain_sqr, d29, blocks, 256, it);
         printf("  sqr 9x29 blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it / ms / 1e6);
         ms = run(k32_chain_add, d32, blocks, 256, it);
-        printf("  add 8x32 blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it * 2 / ms / 1e6);
+        printf("  library add blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it * 2 / ms / 1e6);
         ms = run(k29_chain_add, d29, blocks, 256, it);
         printf("  add 9x29 blocks=%5d  %8.2f G/s\n", blocks, (double)blocks * 256 * it * 2 / ms / 1e6);
     }
