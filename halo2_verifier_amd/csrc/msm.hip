@@ -411,6 +411,11 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
 __device__ __forceinline__ const G1JSlot* msm_piece_src(const G1JSlot* __restrict__ partial, uint32_t i, uint32_t i0, uint32_t off) {
     return partial + 2 * (size_t)i + ((i == i0 && off > i0 * MSM_CHUNK) ? 1 : 0);
 }
+__device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial, uint32_t i0, uint32_t i1, uint32_t off, G1JSlot* __restrict__ out) {
+    G1J acc = msm_piece_src(partial, i0, i0, off)->p;
+    for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, msm_piece_src(partial, i, i0, off)->p);
+    *out = acc;
+}
 // after the scatter `cursor` is free: it becomes the list of heavy buckets, counts[nb] their number
 __global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                                 uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
@@ -421,8 +426,11 @@ __global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, c
     const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
     if (i0 == i1) return;  // written whole by its chunk
     if (i1 - i0 >= MSM_FIXUP_SERIAL) { heavy[atomicAdd(&counts[nb], 1u)] = b; return; }
-    G1J acc = *msm_piece_src(partial, i0, i0, off);
-    for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off));
+    // in-register additions; pieces of one bucket can coincide or cancel (the same point in two chunks): complete formulas then
+    G1J acc = msm_piece_src(partial, i0, i0, off)->p;
+    bool ok = true;
+    for (uint32_t i = i0 + 1; i <= i1 && ok; ++i) ok = g1_add_fast(acc, msm_piece_src(partial, i, i0, off)->p);
+    if (!ok) { msm_fixup_slow(partial, i0, i1, off, bucket_pts + b); return; }
     bucket_pts[b] = acc;
 }
 __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
