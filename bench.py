@@ -305,7 +305,8 @@ def main():
                          "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if world == 1 else "HIP events, pipelined",
                          "alu": {"note": "the stage is bound by 32-bit integer multiply issue, not by HBM: achieved Fq products/s of the stage against the "
                                          "measured chip-wide peak of the Montgomery product (tools/limb29_microbench.hip)",
-                                 "fq_products_per_term": 2 * 12 * 11, "achieved_Gprod_s": (2 * 12 * 11 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0,
+                                 "fq_products_per_term": 2 * 12 * 11, "fq_products_per_term_note": "2 GLV halves x 12 windows (c = 11, the 1024-proof step) x 11 per mixed addition",
+                                 "achieved_Gprod_s": (2 * 12 * 11 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0,
                                  "peak_Gprod_s": 168.0}},
             "stages_ms": stages,
             "stages_ms_one_launch_in_flight": isolated if world == 1 else None,
