@@ -271,7 +271,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     const uint64_t n = 1ULL << vk.k;
     size_t total_inst = 0;
     for (size_t l : col_lens) total_inst += l;
-    if (total_inst > 4096) { err = "more than 4096 instance values per proof are not supported by this build"; return H2V_ERR_INSTANCE_TOO_LARGE; }
+    if (total_inst > (1u << 20)) { err = "more than 2^20 instance values per proof are not supported by this build"; return H2V_ERR_INSTANCE_TOO_LARGE; }
     for (size_t l : col_lens) if (l > n) { err = "instance column longer than the domain"; return H2V_ERR_INSTANCE_TOO_LARGE; }
     plan.col_lens = col_lens; plan.n_instance_values = (uint32_t)total_inst;
 

@@ -183,6 +183,7 @@ static Setup* make_setup(const Circuit& c, const uint8_t* srs, size_t srs_len, u
     return s;
 }
 void* h2o_setup_vector_mul(uint32_t k, size_t n_mul, const uint8_t* srs, size_t srs_len, uint64_t s_seed) {
+    if (k > 24 || 3 * n_mul + 8 > (size_t(1) << k)) return nullptr;  // the circuit uses 3 rows per multiplication and needs the blinding rows free
     try { Setup* s = make_setup(circuit_vector_mul(k, n_mul), srs, srs_len, s_seed); if (s) { s->kind = 0; s->n_mul = n_mul; } return s; } catch (...) { return nullptr; }
 }
 void* h2o_setup_shuffle(uint32_t k, size_t W, size_t H, const uint8_t* srs, size_t srs_len, uint64_t s_seed) {

@@ -144,3 +144,25 @@ def test_reference_strategy_surface():
     assert st.finalize() is False
     assert h2v.AccumulatorStrategy(params).finalize() is True   # empty accumulator
     s.free()
+
+
+def test_many_public_inputs():
+    """Instance evaluation (lib.rs:173-218) with thousands of public inputs — the shape of the reference's
+    serialize/examples/vector_mul.rs, which exposes 2^19 products (here 5000, past the first build's 4096 cap): the per-input
+    Lagrange terms, their share of the one batched inversion and the 33 absorbed bytes per input all scale with the count."""
+    import random
+    import halo2_verifier_amd as h2v
+    from circuits import R_MOD
+    s = circuits.setup_vector_mul(14, 5000)
+    P, I = circuits.prove_vector_mul_batch(s, 3, seed=11, threads=3)
+    ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
+    rnd = random.Random(5)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(3)]
+    got = ctx.verify_batch(P, I, rand)
+    assert got == circuits.oracle_verify_batch(s, P, I, rand) and got[0] is True
+    I2 = list(I)
+    I2[2] = [I[2][0][:4999] + [circuits.le32(9)]]          # the LAST public input is wrong
+    bad = ctx.verify_batch(P, I2, rand)
+    assert bad == circuits.oracle_verify_batch(s, P, I2, rand) and bad[0] is False
+    assert ctx.verify_each(P, I2) == [0, 0, -2]
+    ctx.close(); s.free()
