@@ -26,7 +26,7 @@
 //                   64 chunks — skewed inputs — go to msm_fixup_heavy, one workgroup each) and writes the identity for
 //                   empty buckets
 //   5. msm_window   one wave (four for more than 2048 buckets) per (problem, window): sum_b (b+1) * bucket[b] by per-lane
-//                   running sums over a slice of buckets, then a tree reduction through LDS
+//                   running sums over a slice of buckets, then a cross-lane butterfly (wave shuffles; LDS tree for four waves)
 //   6. msm_final    one lane per problem: Horner over windows (c doublings + one add per window)
 //
 // Steps 1-3 are a hand-written counting sort (no atomics on points, no library sort); the only
@@ -479,6 +479,21 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
             if ((lo >> i) & 1) scaled = g1_add(scaled, run);
         }
         sum = g1_add(sum, scaled);
+    }
+    if (T <= 64) {
+        // a single wave: butterfly over the lanes with cross-lane moves (27 dwords per step), no LDS and no barrier;
+        // lanes beyond T hold the identity
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            G1J other;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&sum);
+#pragma unroll
+            for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 64);
+            if (t + d >= T) other = G1J::identity();
+            sum = g1_add(sum, other);
+        }
+        if (t == 0) window_sums[(size_t)q * p.windows + w] = sum;
+        return;
     }
     red[t] = sum;
     __syncthreads();
