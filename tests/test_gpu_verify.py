@@ -221,3 +221,25 @@ def test_lookup_heavy_vk_shape():
     bad, inst_b = circuits.prove_wide(s, witness_seed=0, tamper=True)
     assert ctx.verify_each([P[0], bad], [I[0], inst_b]) == [0, -2]
     ctx.close(); s.free()
+
+
+def test_bench_configuration_k14():
+    """BASELINE.json config 2's circuit size: k = 14 (omega, n^-1 and the blinding rows follow k; the verifier's work does
+    not), 8 public inputs, known-s SRS with the bench's seed.  Guard MSM, challenges, accumulators and verdicts against the
+    oracle, plus a wrong public input."""
+    s = circuits.setup_vector_mul(14, 8, s_seed=0x48325630)
+    ctx = _ctx(s)
+    P, I = circuits.prove_vector_mul_batch(s, 6, seed=0x48325630, threads=6)
+    assert len(P[0]) == 1024
+    for i in range(2):
+        assert _check_guard(ctx, s, P[i], I[i]) == 0
+    rnd = random.Random(14)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(6)]
+    got = ctx.verify_batch(P, I, rand)
+    assert got == circuits.oracle_verify_batch(s, P, I, rand) and got[0] is True
+    I2 = list(I)
+    I2[4] = [[circuits.le32(1)] + I[4][0][1:]]
+    bad = ctx.verify_batch(P, I2, rand)
+    assert bad == circuits.oracle_verify_batch(s, P, I2, rand) and bad[0] is False
+    assert ctx.verify_each(P, I2) == [0, 0, 0, 0, -2, 0]
+    ctx.close(); s.free()
