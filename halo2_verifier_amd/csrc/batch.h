@@ -34,8 +34,6 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult);
 int frvm_enqueue(hipStream_t s, const FrvmArgs& a);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal);
-int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const uint32_t* d_left_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np,
-                       uint32_t n_shared, G1J* d_pairs);
 }  // namespace h2v
 
 struct h2v_batch {
@@ -46,15 +44,14 @@ struct h2v_batch {
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
     uint32_t n = 0, n_tail = 0;
     uint32_t groups = 1;              // independent accumulator batches inside this launch (h2v_batch_set_groups)
-    bool launched = false, with_pairing = false, single = false;
+    bool launched = false, with_pairing = false;
     // device buffers (sized for max_proofs with the plan of the first upload; re-allocated if a later plan needs more)
     uint8_t* proofs = nullptr; uint8_t* inst = nullptr; uint8_t* tail = nullptr;
     h2v::G1A* pts = nullptr; uint8_t* ycanon = nullptr; int* status = nullptr;
     unsigned long long* words = nullptr; h2v::Fr* chal = nullptr; h2v::Fr* mult = nullptr; h2v::Fr* slots = nullptr;
     uint32_t* msm_scal = nullptr; h2v::Fr* shared = nullptr; uint32_t* left_scal = nullptr;
     h2v::G1J* acc = nullptr;      // per group: [2g] left, [2g+1] right
-    h2v::G1J* pairs = nullptr;    // per-proof channels (SingleStrategy)
-    uint32_t* ok = nullptr;       // [max(max_proofs, groups)]: per proof (SingleStrategy) or per group
+    uint32_t* ok = nullptr;       // [groups]
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
     h2v::MsmWorkspace ws;
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;

@@ -39,8 +39,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
     if ((rc = dev_alloc(b->left_scal, N * pl.n_points * 8))) return rc;
     if ((rc = dev_alloc(b->acc, 2 * G))) return rc;
-    if ((rc = dev_alloc(b->pairs, 2 * N))) return rc;
-    if ((rc = dev_alloc(b->ok, std::max(N, G)))) return rc;
+    if ((rc = dev_alloc(b->ok, G))) return rc;
     if ((rc = dev_alloc(b->out_bytes, 128 * G))) return rc;
     if ((rc = dev_alloc(b->out_ident, 2 * G))) return rc;
     if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + G * pl.n_shared)), (uint32_t)(2 * G), (uint32_t)((N + G - 1) / G * pl.n_points + pl.n_shared)))) return rc;
@@ -107,7 +106,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     return 0;
 }
 
-int launch_impl(h2v_batch* b, int with_pairing, bool single) {
+int launch_impl(h2v_batch* b, int with_pairing) {
     if (!b || !b->plan) { set_last_error("h2v_batch_launch: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
     h2v_ctx* ctx = b->ctx;
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
@@ -116,8 +115,7 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
     hipStream_t s = b->stream;
     uint32_t n = b->n;
     const uint32_t G = b->groups, gs = n / G;
-    if (single && G > 1) { set_last_error("a grouped batch cannot run the per-proof (SingleStrategy) path"); return H2V_ERR_BAD_ARGUMENT; }
-    b->with_pairing = with_pairing != 0; b->single = single; b->launched = true;
+    b->with_pairing = with_pairing != 0; b->launched = true;
     int rc;
     int ev = 0;
     auto mark = [&]() { if (b->profiling) hipEventRecord(b->ev[ev], s); ++ev; };
@@ -134,13 +132,6 @@ int launch_impl(h2v_batch* b, int with_pairing, bool single) {
                b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal};
     if ((rc = frvm_enqueue(s, a))) return rc;
     mark();
-    if (single) {
-        if ((rc = single_msm_enqueue(s, b->msm_scal, b->left_scal, b->shared, b->pts, n, pl.n_points, pl.n_shared, b->pairs))) return rc;
-        mark(); mark();
-        if ((rc = pairing_check_enqueue(s, ctx->pairing, b->pairs, n, b->ok))) return rc;
-        mark();
-        return 0;
-    }
     if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, G, b->msm_scal))) return rc; }
     mark();
     {   // both channels of every group in one set of launches: [2g] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points),
@@ -170,14 +161,11 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     hipStream_t s = b->stream;
     const uint32_t n = b->n, G = b->groups, gs = n / G;
     std::vector<int> st(n ? n : 1, 0);
-    std::vector<uint32_t> okv(b->single ? (n ? n : 1) : G, 1);
+    std::vector<uint32_t> okv(G, 1);
     std::vector<uint8_t> outb(128 * (size_t)G, 0);
     if (n) H2V_HIP_CHECK(hipMemcpyAsync(st.data(), b->status, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-    if (b->single) { if (n) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * n, hipMemcpyDeviceToHost, s)); }
-    else {
-        if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
-        H2V_HIP_CHECK(hipMemcpyAsync(outb.data(), b->out_bytes, 128 * (size_t)G, hipMemcpyDeviceToHost, s));
-    }
+    if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipMemcpyAsync(outb.data(), b->out_bytes, 128 * (size_t)G, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_last_error(std::string("h2v_batch_finish: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
     if (b->profiling) {
@@ -190,12 +178,11 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     std::vector<char> all_ok(G, 1);
     for (uint32_t i = 0; i < n; ++i) {
         int v = st[i];
-        if (b->single && v == 0 && !okv[i]) v = H2V_ERR_CONSTRAINT_SYSTEM_FAILURE;  // kzg/strategy.rs:171-175
         if (per_proof_status) per_proof_status[i] = v;
         if (v != 0) all_ok[i / gs] = 0;
     }
     for (uint32_t g = 0; g < G; ++g) {
-        if (group_ok) group_ok[g] = b->single ? (all_ok[g] ? 1 : 0) : ((all_ok[g] && (!b->with_pairing || okv[g])) ? 1 : 0);
+        if (group_ok) group_ok[g] = (all_ok[g] && (!b->with_pairing || okv[g])) ? 1 : 0;
         if (out_left) memcpy(out_left + 64 * (size_t)g, &outb[128 * (size_t)g], 64);
         if (out_right) memcpy(out_right + 64 * (size_t)g, &outb[128 * (size_t)g + 64], 64);
     }
@@ -231,13 +218,36 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
         if (per_inst) { if (!instances32 || !instances32[i]) { set_last_error("null instances pointer"); return H2V_ERR_BAD_ARGUMENT; } memcpy(&iflat[i * per_inst], instances32[i], per_inst); }
     }
     h2v_batch* b = nullptr;
+    if (single) {
+        // SingleStrategy (kzg/strategy.rs:143-181) = an accumulator of ONE proof with multiplier 1 and its own pairing: run the
+        // proofs as one-proof groups of grouped launches, at most MSM_MAX_PROBLEMS / 2 per launch
+        const size_t per = MSM_MAX_PROBLEMS / 2;
+        if ((rc = h2v_batch_create(ctx, std::min(n ? n : 1, per), pl.n_instance_values, &b))) return rc;
+        bool all = true;
+        for (size_t off = 0; off < n && !rc; off += per) {
+            const size_t m = std::min(per, n - off);
+            std::vector<uint8_t> ones(32 * m, 0);
+            for (size_t i = 0; i < m; ++i) ones[32 * i] = 1;
+            std::vector<int> st(m, 0), gok(m, 0);
+            if ((rc = h2v_batch_set_groups(b, m))) break;
+            if ((rc = upload_impl(b, m, flat.data() + off * pl.proof_len, pl.proof_len, iflat.data() + off * per_inst, ncols, col_lens, ones.data(), m))) break;
+            if ((rc = launch_impl(b, 1))) break;
+            if ((rc = finish_impl(b, st.data(), gok.data(), nullptr, nullptr))) break;
+            for (size_t i = 0; i < m; ++i) {
+                int v = forced[off + i] ? forced[off + i] : st[i];
+                if (v == 0 && !gok[i]) v = H2V_ERR_CONSTRAINT_SYSTEM_FAILURE;  // kzg/strategy.rs:171-175
+                if (per_proof_status) per_proof_status[off + i] = v;
+                if (v != 0) all = false;
+            }
+        }
+        if (batch_ok && !rc) *batch_ok = all ? 1 : 0;
+        h2v_batch_destroy(b);
+        return rc;
+    }
     if ((rc = h2v_batch_create(ctx, n ? n : 1, pl.n_instance_values, &b))) return rc;
     do {
-        std::vector<uint8_t> ones;
-        const uint8_t* tail = rand32;
-        if (single) { ones.assign(32 * (n ? n : 1), 0); for (size_t i = 0; i < n; ++i) ones[32 * i] = 1; tail = ones.data(); }
-        if ((rc = upload_impl(b, n, flat.data(), pl.proof_len, iflat.data(), ncols, col_lens, tail, tail ? n : 0))) break;
-        if ((rc = launch_impl(b, with_pairing, single))) break;
+        if ((rc = upload_impl(b, n, flat.data(), pl.proof_len, iflat.data(), ncols, col_lens, rand32, rand32 ? n : 0))) break;
+        if ((rc = launch_impl(b, with_pairing))) break;
         std::vector<int> st(n ? n : 1, 0);
         int ok = 0;
         if ((rc = finish_impl(b, st.data(), &ok, out_left, out_right))) break;
@@ -285,7 +295,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
-    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->acc); hipFree(b->pairs); hipFree(b->ok);
+    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->acc); hipFree(b->ok);
     hipFree(b->out_bytes); hipFree(b->out_ident);
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
@@ -297,7 +307,7 @@ int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t 
                      const size_t* col_lens, const uint8_t* rand32_tail, size_t n_tail) {
     return upload_impl(b, n, proofs_flat, proof_len, instances_flat, n_instance_columns, col_lens, rand32_tail, n_tail);
 }
-int h2v_batch_launch(h2v_batch* b, int with_pairing) { return launch_impl(b, with_pairing, false); }
+int h2v_batch_launch(h2v_batch* b, int with_pairing) { return launch_impl(b, with_pairing); }
 int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
     if (b && b->groups > 1) { set_last_error("h2v_batch_finish: the batch is grouped, use h2v_batch_finish_groups"); return H2V_ERR_BAD_ARGUMENT; }
     return finish_impl(b, per_proof_status, batch_ok, out_left_xy, out_right_xy);

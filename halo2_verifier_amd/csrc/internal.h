@@ -41,7 +41,7 @@ struct MsmProblem {
     MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n1_, const uint32_t* s2, const G1A* b2, uint32_t n2)
         : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n1_ + n2), n1(n1_), scalars2(s2), bases2(b2) {}
 };
-#define MSM_MAX_PROBLEMS 256      // per launch (a grouped batch: two channels per group)
+#define MSM_MAX_PROBLEMS 1024     // per launch (a grouped batch: two channels per group; SingleStrategy: one group per proof)
 #define MSM_PROBLEM_CHUNK 16      // descriptors handed to the device per setter launch (kernel-argument space)
 struct MsmProblemChunk { MsmProblem p[MSM_PROBLEM_CHUNK]; };
 struct MsmProblems { std::vector<MsmProblem> p; };

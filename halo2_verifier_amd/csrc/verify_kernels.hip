@@ -8,7 +8,6 @@
 //   k_multipliers     one workgroup                 suffix products of the batch draws kzg/strategy.rs:129, msm.rs:173-176
 //   k_frvm            one lane per proof            the compiled Fr program            lib.rs:173-346, shplonk.rs:202-264
 //   k_fold_shared     one workgroup per shared base sum over proofs of the scalars of VK-wide bases
-//   k_single_msm      one lane per proof            per-proof channels for SingleStrategy   kzg/strategy.rs:164-176
 //
 // Layouts are chosen so that lanes (= proofs) are contiguous in the fastest dimension for
 // everything the per-proof kernels re-read: stream words [word][proof], challenges [c][proof],
@@ -370,48 +369,6 @@ __global__ void __launch_bounds__(256) k_fold_shared(const Fr* __restrict__ shar
     }
 }
 
-// SingleStrategy: each proof's own two channels (left = sum left_scal * own points, right = its full Guard MSM), no pooling.
-__global__ void __launch_bounds__(64) k_single_msm(const uint32_t* __restrict__ msm_scal, const uint32_t* __restrict__ left_scal, const Fr* __restrict__ shared,
-                                                   const G1A* __restrict__ pts, uint32_t n, uint32_t np, uint32_t n_shared, G1J* __restrict__ pairs) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const G1A* shared_bases = pts + (size_t)n * np;
-    G1J acc = G1J::identity();
-    for (int bit = 253; bit >= 0; --bit) {
-        acc = g1_dbl(acc);
-        for (uint32_t s = 0; s < np; ++s) {
-            uint32_t w = msm_scal[((size_t)p * np + s) * 8 + (bit >> 5)];
-            if ((w >> (bit & 31)) & 1) acc = g1_add_affine(acc, pts[(size_t)p * np + s]);
-        }
-    }
-    // shared bases: scalars are Montgomery in shared[j][p]
-    for (uint32_t j = 0; j < n_shared; ++j) {
-        uint32_t raw[8];
-        shared[(size_t)j * n + p].to_raw(raw);
-        G1J t = G1J::identity();
-        for (int bit = 253; bit >= 0; --bit) {
-            t = g1_dbl(t);
-            if ((raw[bit >> 5] >> (bit & 31)) & 1) t = g1_add_affine(t, shared_bases[j]);
-        }
-        acc = g1_add(acc, t);
-    }
-    // left channel: the few slots with a non-zero left scalar (h2 for SHPLONK, the witness points for GWC)
-    G1J left = G1J::identity();
-    for (uint32_t s = 0; s < np; ++s) {
-        const uint32_t* k = left_scal + ((size_t)p * np + s) * 8;
-        uint32_t nz = 0;
-        for (int i = 0; i < 8; ++i) nz |= k[i];
-        if (!nz) continue;
-        G1J t = G1J::identity();
-        for (int bit = 253; bit >= 0; --bit) {
-            t = g1_dbl(t);
-            if ((k[bit >> 5] >> (bit & 31)) & 1) t = g1_add_affine(t, pts[(size_t)p * np + s]);
-        }
-        left = g1_add(left, t);
-    }
-    pairs[2 * (size_t)p] = left;
-    pairs[2 * (size_t)p + 1] = acc;
-}
 
 // ------------------------------------------------------------------ launchers
 int decompress_stage_enqueue(hipStream_t s, const StageArgs& g) {
@@ -454,12 +411,6 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a) {
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal) {
     if (!n_shared) return 0;
     hipLaunchKernelGGL(k_fold_shared, dim3(n_shared, groups), dim3(256), 0, s, d_shared, n, np, n / groups, d_msm_scal);
-    H2V_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-int single_msm_enqueue(hipStream_t s, const uint32_t* d_msm_scal, const uint32_t* d_left_scal, const Fr* d_shared, const G1A* d_pts, uint32_t n, uint32_t np, uint32_t n_shared, G1J* d_pairs) {
-    if (!n) return 0;
-    hipLaunchKernelGGL(k_single_msm, dim3((n + 63) / 64), dim3(64), 0, s, d_msm_scal, d_left_scal, d_shared, d_pts, n, np, n_shared, d_pairs);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
