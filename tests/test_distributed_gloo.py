@@ -80,3 +80,35 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _worker_groups(rank, world, port, G, q):
+    sys.path.insert(0, ROOT)
+    from halo2_verifier_amd import distributed as h2d
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # what Batch.export_accumulators writes for a grouped launch: [group][left, right] opaque bytes
+    local = torch.tensor([(rank * 131 + g * 17 + k) % 251 for g in range(G) for k in range(h2d.ACC_BYTES)], dtype=torch.uint8)
+    gathered = h2d.gather_accumulators(local, world)
+    ok = gathered.numel() == world * G * h2d.ACC_BYTES
+    for r in range(world):
+        for g in range(G):
+            off = (r * G + g) * h2d.ACC_BYTES     # the [rank][group] layout h2v_batch_fold_check_enqueue folds
+            want = [(r * 131 + g * 17 + k) % 251 for k in range(h2d.ACC_BYTES)]
+            ok = ok and gathered[off:off + h2d.ACC_BYTES].tolist() == want
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grouped_accumulators_gather_in_rank_major_order():
+    """A grouped launch exchanges all its groups in ONE collective; the fold kernel indexes the result as [rank][group]."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_groups, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=5) is True
