@@ -1,0 +1,171 @@
+// C++ host-side mirror of the reference's surface for the accelerated path, over the C ABI in h2v.h.
+//
+// The reference is a Rust crate; a Rust toolchain is not available where this library is built, so the host side
+// above the C ABI is offered in C++ (this header; header-only, C++17) and in Python (halo2_verifier_amd/verifier.py),
+// and as uncompiled Rust source in integration/rust/.  Names, argument meaning and error behaviour follow the reference:
+//
+//   reference (halo2_verifier)                                   here (namespace halo2_verifier)
+//   ---------------------------------------------------------    ---------------------------------------------
+//   helpers::SerdeFormat                  helpers.rs:7-19         SerdeFormat
+//   plonk::Error                          plonk/mod.rs:19-32      Error (same order: InvalidInstances = -1 ...)
+//   ParamsKZG::read_custom                kzg/commitment.rs:155   ParamsKZG(bytes, format)
+//   VerifyingKey::read                    plonk/vk.rs:76-115      VerifyingKey(bytes, format)
+//   verify_proof(params, vk, strategy, instances, transcript)     verify_proof(params, vk, strategy, instances, proof)
+//                                         lib.rs:33-49
+//   AccumulatorStrategy::{new, process, finalize}                 AccumulatorStrategy(params): verify_proof() queues,
+//                                         kzg/strategy.rs:99-141    finalize() runs the batch on the GPU
+//   SingleStrategy                        kzg/strategy.rs:143-181 SingleStrategy(params): verify_proof() runs at once
+//   VerifierSHPLONK / VerifierGWC, Blake2bRead / Keccak256Read    MultiOpen, TranscriptKind (generic parameters of lib.rs:33-40)
+//
+// There is no CPU fallback: constructing a Context without a HIP device throws Failure{H2V_ERR_DEVICE}.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "h2v.h"
+
+namespace halo2_verifier {
+
+enum class SerdeFormat : int { Processed = H2V_SERDE_PROCESSED, RawBytes = H2V_SERDE_RAW_BYTES, RawBytesUnchecked = H2V_SERDE_RAW_BYTES_UNCHECKED };
+enum class MultiOpen : int { SHPLONK = H2V_MULTIOPEN_SHPLONK, GWC = H2V_MULTIOPEN_GWC };
+enum class TranscriptKind : int { Blake2b = H2V_TRANSCRIPT_BLAKE2B, Keccak256 = H2V_TRANSCRIPT_KECCAK256 };
+
+// plonk::Error (plonk/mod.rs:19-32), in declaration order
+enum class Error : int {
+    Ok = 0,
+    InvalidInstances = H2V_ERR_INVALID_INSTANCES,
+    ConstraintSystemFailure = H2V_ERR_CONSTRAINT_SYSTEM_FAILURE,
+    BoundsFailure = H2V_ERR_BOUNDS_FAILURE,
+    Opening = H2V_ERR_OPENING,
+    Transcript = H2V_ERR_TRANSCRIPT,
+    InstanceTooLarge = H2V_ERR_INSTANCE_TOO_LARGE,
+};
+
+// a failure of the library itself (bad argument, malformed VK / params, no device), as opposed to a proof that does not verify
+struct Failure : std::runtime_error {
+    int code;
+    Failure(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+inline void check(int rc) { if (rc != 0) throw Failure(rc, h2v_last_error()); }
+
+typedef std::vector<uint8_t> Bytes;
+typedef std::vector<Bytes> Column;            // one instance column: 32-byte little-endian canonical Fr values
+typedef std::vector<Column> Instances;        // one circuit instance: its columns (the reference's &[&[Fr]])
+
+struct ParamsKZG { Bytes bytes; SerdeFormat format = SerdeFormat::RawBytes; };
+struct VerifyingKey { Bytes bytes; SerdeFormat format = SerdeFormat::RawBytes; };
+
+// ParamsKZG + VerifyingKey resident on one GPU (h2v_ctx)
+class Context {
+public:
+    Context(const ParamsKZG& p, const VerifyingKey& vk, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b) {
+        h2v_options o{(int)mo, (int)tr};
+        check(h2v_ctx_create_ex(p.bytes.data(), p.bytes.size(), (int)p.format, vk.bytes.data(), vk.bytes.size(), (int)vk.format, device, &o, &h_));
+    }
+    ~Context() { if (h_) h2v_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    h2v_ctx* handle() const { return h_; }
+
+private:
+    h2v_ctx* h_ = nullptr;
+};
+
+namespace detail {
+// pointer-array view of (proof, instances) pairs in the layout h2v_verify_batch / h2v_verify_each take
+struct Packed {
+    std::vector<const uint8_t*> proofs, insts;
+    std::vector<size_t> lens, col_lens;
+    std::vector<Bytes> flat;
+    Packed(const std::vector<std::pair<Instances, Bytes>>& items, size_t ncols_if_empty) {
+        for (const auto& it : items) {
+            Bytes f;
+            for (const Column& c : it.first) for (const Bytes& v : c) f.insert(f.end(), v.begin(), v.end());
+            flat.push_back(std::move(f));
+        }
+        for (size_t i = 0; i < items.size(); ++i) {
+            proofs.push_back(items[i].second.data()); lens.push_back(items[i].second.size()); insts.push_back(flat[i].data());
+        }
+        if (!items.empty()) for (const Column& c : items[0].first) col_lens.push_back(c.size());
+        else col_lens.assign(ncols_if_empty, 0);
+        for (const auto& it : items) {
+            if (it.first.size() != col_lens.size()) throw Failure(H2V_ERR_INVALID_INSTANCES, "instances do not match the VK's instance column count");
+            for (size_t c = 0; c < col_lens.size(); ++c)
+                if (it.first[c].size() != col_lens[c]) throw Failure(H2V_ERR_BAD_ARGUMENT, "all proofs of one batch share one instance shape");
+        }
+    }
+};
+}  // namespace detail
+
+// kzg/strategy.rs:99-141: verify_proof() adds a proof to the accumulator, finalize() runs ONE pairing for all of them.
+// Here the proofs are queued on the host and the whole batch runs on the GPU at finalize().
+class AccumulatorStrategy {
+public:
+    explicit AccumulatorStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b)
+        : params_(p), device_(device), mo_(mo), tr_(tr) {}
+    // rand32: the Fr::random draws of process() (kzg/strategy.rs:129), one 32-byte canonical scalar per proof; empty = OS RNG
+    void set_randomness(Bytes rand32) { rand_ = std::move(rand32); }
+    void push(const VerifyingKey& vk, Instances inst, Bytes proof) {
+        if (!items_.empty() && vk.bytes != vk_.bytes) throw Failure(H2V_ERR_BAD_ARGUMENT, "one AccumulatorStrategy batch verifies proofs of one VerifyingKey");
+        vk_ = vk;
+        items_.emplace_back(std::move(inst), std::move(proof));
+    }
+    // -> true iff every verify_proof succeeded and the pairing check passed; statuses() then holds the per-proof plonk::Error
+    bool finalize() {
+        Context ctx(params_, vk_, device_, mo_, tr_);
+        size_t ncols = 0;
+        check(h2v_ctx_proof_shape(ctx.handle(), nullptr, nullptr, nullptr, nullptr, &ncols));
+        detail::Packed pk(items_, ncols);
+        statuses_.assign(items_.size() ? items_.size() : 1, 0);
+        int ok = 0;
+        if (!rand_.empty() && rand_.size() != 32 * items_.size()) throw Failure(H2V_ERR_BAD_ARGUMENT, "one 32-byte draw per proof");
+        check(h2v_verify_batch(ctx.handle(), items_.size(), pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens.data(),
+                               rand_.empty() ? nullptr : rand_.data(), statuses_.data(), &ok, left_, right_));
+        statuses_.resize(items_.size());
+        return ok != 0;
+    }
+    const std::vector<int>& statuses() const { return statuses_; }
+    const uint8_t* left() const { return left_; }     // evaluated channels of the final DualMSM, canonical x|y
+    const uint8_t* right() const { return right_; }
+
+private:
+    ParamsKZG params_; VerifyingKey vk_; int device_; MultiOpen mo_; TranscriptKind tr_;
+    std::vector<std::pair<Instances, Bytes>> items_;
+    Bytes rand_;
+    std::vector<int> statuses_;
+    uint8_t left_[64] = {0}, right_[64] = {0};
+};
+
+// kzg/strategy.rs:143-181: one pairing per proof, checked inside verify_proof
+class SingleStrategy {
+public:
+    explicit SingleStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b)
+        : params_(p), device_(device), mo_(mo), tr_(tr) {}
+    Error verify(const VerifyingKey& vk, const Instances& inst, const Bytes& proof) const {
+        Context ctx(params_, vk, device_, mo_, tr_);
+        std::vector<std::pair<Instances, Bytes>> one{{inst, proof}};
+        size_t ncols = 0;
+        check(h2v_ctx_proof_shape(ctx.handle(), nullptr, nullptr, nullptr, nullptr, &ncols));
+        if (inst.size() != ncols) return Error::InvalidInstances;   // lib.rs:51-55
+        detail::Packed pk(one, ncols);
+        int st = 0;
+        check(h2v_verify_each(ctx.handle(), 1, pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens.data(), &st));
+        return (Error)st;
+    }
+
+private:
+    ParamsKZG params_; int device_; MultiOpen mo_; TranscriptKind tr_;
+};
+
+// lib.rs:33-49.  SingleStrategy: returns the proof's plonk::Error (Ok = accepted).
+inline Error verify_proof(const ParamsKZG&, const VerifyingKey& vk, const SingleStrategy& s, const Instances& inst, const Bytes& proof) { return s.verify(vk, inst, proof); }
+// AccumulatorStrategy: Output = the strategy (the proof is queued; errors surface in statuses() after finalize())
+inline AccumulatorStrategy& verify_proof(const ParamsKZG&, const VerifyingKey& vk, AccumulatorStrategy& s, Instances inst, Bytes proof) {
+    s.push(vk, std::move(inst), std::move(proof));
+    return s;
+}
+
+}  // namespace halo2_verifier

@@ -75,3 +75,9 @@ def test_product_does_not_link_or_import_the_oracle():
                         # comments that say "shares no code with oracle/" are the only allowed mentions
                         lines = [l for l in text.splitlines() if needle in l and not l.strip().startswith(("//", "#", "*", '"""')) and "no code with oracle" not in l]
                         assert not lines, (f, lines)
+
+
+def test_cpp_mirror_header_compiles():
+    """include/h2v.hpp (the C++ host-side mirror of the reference surface) and its harness are valid C++17 against h2v.h."""
+    import subprocess
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "harness.cpp")], check=True)
