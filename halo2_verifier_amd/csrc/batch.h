@@ -17,7 +17,20 @@ struct FrvmArgs {
     uint32_t* msm_scal; uint32_t np;
     Fr* shared;
     uint32_t* left_scal;
+    const Fr* insteval;   // [query][proof], wide instance vectors only
 };
+
+// sum_j inst[base + j] * l_{j - rot}(x) for one instance query of every proof (lib.rs:173-218; l_i_range poly/domain.rs:187-212)
+struct InstEvalArgs {
+    const uint8_t* inst; uint32_t ninst;      // canonical instance bytes [proof][ninst][32]
+    const Fr* chal; uint32_t x_chal;          // challenges [c][proof]; index of x
+    uint32_t n, k;                            // proofs; domain size 2^k
+    uint32_t base, len;                       // the query's column inside a proof's instance values
+    Fr w_start, omega, omega_step, omega_step_inv, n_inv;   // omega^(-rot), omega, omega^256, omega^(-256), 1/2^k
+    Fr* out;                                  // [proof]
+    int* status;
+};
+int instance_eval_enqueue(hipStream_t s, const InstEvalArgs& a);
 
 struct StageArgs {
     uint32_t n;
@@ -50,6 +63,7 @@ struct h2v_batch {
     h2v::G1A* pts = nullptr; uint8_t* ycanon = nullptr; int* status = nullptr;
     unsigned long long* words = nullptr; h2v::Fr* chal = nullptr; h2v::Fr* mult = nullptr; h2v::Fr* slots = nullptr;
     uint32_t* msm_scal = nullptr; h2v::Fr* shared = nullptr; uint32_t* left_scal = nullptr;
+    h2v::Fr* insteval = nullptr;  // [query][proof] (wide instance vectors)
     h2v::G1J* acc = nullptr;      // per group: [2g] left, [2g+1] right
     uint32_t* ok = nullptr;       // [groups]
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;

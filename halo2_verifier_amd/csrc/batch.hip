@@ -19,7 +19,7 @@ template <class T> int dev_alloc(T*& p, size_t count) {
 int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     const Plan& pl = pd->host;
     size_t N = b->max_proofs, G = b->groups;
-    size_t sig = G * 7919u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
+    size_t sig = G * 7919u + pl.inst_queries.size() * 31u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
     if (b->cap_plan_sig == sig && b->pts) return 0;
     int rc;
     uint32_t words = (uint32_t)((pl.stream.size() + 7) / 8);
@@ -38,6 +38,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->msm_scal, (N * pl.n_points + G * pl.n_shared) * 8))) return rc;
     if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
     if ((rc = dev_alloc(b->left_scal, N * pl.n_points * 8))) return rc;
+    if ((rc = dev_alloc(b->insteval, N * pl.inst_queries.size()))) return rc;
     if ((rc = dev_alloc(b->acc, 2 * G))) return rc;
     if ((rc = dev_alloc(b->ok, G))) return rc;
     if ((rc = dev_alloc(b->out_bytes, 128 * G))) return rc;
@@ -129,7 +130,17 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     mark();
     if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
-               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal};
+               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval};
+    if (n && pl.wide_instances) {
+        Fr step = pl.omega;
+        for (int i = 0; i < 8; ++i) step = step.sqr();   // omega^256: a thread's stride through the column
+        const Fr step_inv = step.inv();
+        for (size_t q = 0; q < pl.inst_queries.size(); ++q) {
+            InstEvalArgs ia{b->inst, pl.n_instance_values, b->chal, pl.x_chal, n, pl.domain_k, pl.inst_queries[q].base, pl.inst_queries[q].len,
+                            pl.inst_queries[q].w_start, pl.omega, step, step_inv, pl.n_inv, b->insteval + q * (size_t)n, b->status};
+            if ((rc = instance_eval_enqueue(s, ia))) return rc;
+        }
+    }
     if ((rc = frvm_enqueue(s, a))) return rc;
     mark();
     if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, G, b->msm_scal))) return rc; }
@@ -295,7 +306,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
-    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->acc); hipFree(b->ok);
+    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->acc); hipFree(b->ok);
     hipFree(b->out_bytes); hipFree(b->out_ident);
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);

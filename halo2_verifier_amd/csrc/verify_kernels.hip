@@ -6,6 +6,7 @@
 //   k_stream_build    one lane per (proof, 8-byte word of the absorbed stream)         transcript/mod.rs:216-231
 //   k_transcript      one lane per proof            Blake2b-512 + challenges           transcript/mod.rs:124-133,209-214,500-514
 //   k_multipliers     one workgroup                 suffix products of the batch draws kzg/strategy.rs:129, msm.rs:173-176
+//   k_instance_eval   one workgroup per proof       Lagrange sum over a wide instance column   lib.rs:173-218, poly/domain.rs:187-212
 //   k_frvm            one lane per proof            the compiled Fr program            lib.rs:173-346, shplonk.rs:202-264
 //   k_fold_shared     one workgroup per shared base sum over proofs of the scalars of VK-wide bases
 //
@@ -261,6 +262,63 @@ __global__ void __launch_bounds__(1024) k_multipliers(const uint8_t* __restrict_
     }
 }
 
+// Instance evaluation for wide instance vectors (lib.rs:173-218; l_i_range, poly/domain.rs:187-212):
+//   E = sum_j a_j * l_{j-rot}(x),   l_i(x) = omega^i (x^n - 1) / (n (x - omega^i))
+// One workgroup per proof.  Thread t owns j = t, t + 256, ...: omega^(j-rot) advances by omega^256 per step.  The
+// denominators are inverted in chunks of INSTEVAL_CHUNK per thread with Montgomery's trick (prefix products in LDS, one
+// Fermat inversion per chunk, the denominators recomputed on the way back instead of stored); partial sums meet in an LDS
+// tree.  A zero denominator (x on the domain) is reported like the program's zero inversions (H2V_ERR_REFERENCE_PANIC).
+#define INSTEVAL_THREADS 256
+#define INSTEVAL_CHUNK 16
+__global__ void __launch_bounds__(INSTEVAL_THREADS) k_instance_eval(InstEvalArgs a) {
+    extern __shared__ Fr insteval_lds[];                         // [INSTEVAL_CHUNK][256] prefix products, then [256] partial sums
+    Fr* pre = insteval_lds;
+    Fr* red = insteval_lds + (size_t)INSTEVAL_CHUNK * INSTEVAL_THREADS;
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const Fr x = a.chal[(size_t)a.x_chal * a.n + p];
+    Fr w = a.w_start * a.omega.pow_u32(t);                       // omega^(t - rot)
+    Fr acc = Fr::zero();
+    bool zero_den = false;
+    const uint8_t* vals = a.inst + ((size_t)p * a.ninst + a.base) * 32;
+    for (uint32_t j0 = t; j0 < a.len; j0 += INSTEVAL_THREADS * INSTEVAL_CHUNK) {
+        // forward: prefix products of the chunk's denominators
+        Fr run = Fr::one(), wc = w;
+        uint32_t cnt = 0;
+        for (uint32_t c = 0; c < INSTEVAL_CHUNK && j0 + c * INSTEVAL_THREADS < a.len; ++c, ++cnt) {
+            pre[(size_t)c * INSTEVAL_THREADS + t] = run;
+            run = run * (x - wc);
+            wc = wc * a.omega_step;
+        }
+        w = wc;                                                  // start of the thread's next chunk
+        if (run.is_zero()) { zero_den = true; continue; }
+        Fr inv = run.inv_fermat();
+        // backward: 1/d_c = inv * prefix_c, then inv *= d_c; omega^(j-rot) steps back by omega^-256
+        for (uint32_t c = cnt; c-- > 0;) {
+            wc = wc * a.omega_step_inv;
+            const Fr inv_d = inv * pre[(size_t)c * INSTEVAL_THREADS + t];
+            inv = inv * (x - wc);
+            uint8_t tmp[32];
+            const uint8_t* src = vals + (size_t)(j0 + c * INSTEVAL_THREADS) * 32;
+            for (int i = 0; i < 32; ++i) tmp[i] = src[i];
+            Fr v;
+            if (!Fr::from_bytes(tmp, v)) v = Fr::zero();        // non-canonical values were already reported by k_check_scalars
+            acc = acc + v * wc * inv_d;
+        }
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (uint32_t d = INSTEVAL_THREADS / 2; d > 0; d >>= 1) {
+        if (t < d) red[t] = red[t] + red[t + d];
+        __syncthreads();
+    }
+    if (zero_den) status_set(a.status, p, H2V_ERR_REFERENCE_PANIC);
+    if (t == 0) {
+        Fr xn = x;
+        for (uint32_t i = 0; i < a.k; ++i) xn = xn.sqr();
+        a.out[p] = red[0] * (xn - Fr::one()) * a.n_inv;
+    }
+}
+
 // program slots are limb-planar: limb l of slot s of proof p is word (s * 9 + l) * n + p, so that a wave's 64 proofs read 64
 // consecutive words per limb
 __device__ __forceinline__ Fr slot_load(const Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p) {
@@ -322,6 +380,7 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
                 break;
             }
             case OP_LOAD_CHAL: slot_store(a.slots, in.d, n, p, a.chal[(size_t)in.a * n + p]); break;
+            case OP_LOAD_INSTEVAL: slot_store(a.slots, in.d, n, p, a.insteval[(size_t)in.a * n + p]); break;
             case OP_LOAD_MULT: slot_store(a.slots, in.d, n, p, a.mult[p]); break;
             case OP_STORE_MSM: {
                 uint32_t raw[8];
@@ -399,6 +458,14 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
 }
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult) {
     hipLaunchKernelGGL(k_multipliers, dim3(groups), dim3(1024), 0, s, d_tail, n_tail / groups, n / groups, d_mult);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int instance_eval_enqueue(hipStream_t s, const InstEvalArgs& a) {
+    if (!a.n) return 0;
+    const size_t lds = ((size_t)INSTEVAL_CHUNK + 1) * INSTEVAL_THREADS * sizeof(Fr);   // 153 KB: one workgroup per CU
+    H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_instance_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device; cheap
+    hipLaunchKernelGGL(k_instance_eval, dim3(a.n), dim3(INSTEVAL_THREADS), lds, s, a);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -59,6 +59,7 @@ enum VmOp : uint32_t {
     OP_STORE_MSM = 13,    // msm_scalars[proof][point slot b] <- canonical(a)
     OP_STORE_SHARED = 14, // shared[proof][b] <- a (Montgomery)
     OP_STORE_LEFT = 15,   // left_scalars[proof][point slot b] <- canonical(a)
+    OP_LOAD_INSTEVAL = 16, // d <- instance-query evaluation #a of this proof, computed by k_instance_eval (wide instance vectors)
 };
 struct VmInstr { uint32_t op, d, a, b; };
 
@@ -95,6 +96,13 @@ struct Plan {
     // instance shape this plan was compiled for
     std::vector<size_t> col_lens;
     uint32_t n_instance_values = 0;
+    // Wide instance vectors (more than H2V_WIDE_INSTANCES values): sum_j inst[j] * l_{j-rot}(x) (lib.rs:173-218) is not unrolled
+    // into the Fr program (9 instructions and a slot per public input) but evaluated by k_instance_eval, one workgroup per proof
+    struct InstQuery { uint32_t base, len; Fr w_start; };   // flat offset / length of the column, omega^(-rotation)
+    bool wide_instances = false;
+    std::vector<InstQuery> inst_queries;
+    uint32_t x_chal = 0, domain_k = 0;
+    Fr omega, n_inv;
 };
 // Returns 0 or an H2V error code (InstanceTooLarge, ReferencePanic for an empty gate polynomial, ...)
 int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<size_t>& col_lens, PlanOptions opts, Plan& out, std::string& err);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <array>
 #include <set>
+#include <stdlib.h>
 #include <string.h>
 
 namespace h2v {
@@ -191,6 +192,7 @@ struct Builder {
     Val sqrn(Val a, uint32_t k) { if (k == 0) return a; return push(OP_SQRN, a, 0, k, true); }
     Val load_scalar(uint32_t i) { auto it = scalar_node.find(i); if (it != scalar_node.end()) return it->second; return scalar_node[i] = push(OP_LOAD_SCALAR, 0, 0, i, true); }
     Val load_inst(uint32_t i) { auto it = inst_node.find(i); if (it != inst_node.end()) return it->second; return inst_node[i] = push(OP_LOAD_INST, 0, 0, i, true); }
+    Val load_insteval(uint32_t i) { return push(OP_LOAD_INSTEVAL, 0, 0, i, true); }
     Val load_chal(uint32_t i) { auto it = chal_node.find(i); if (it != chal_node.end()) return it->second; return chal_node[i] = push(OP_LOAD_CHAL, 0, 0, i, true); }
     Val load_mult() { if (mult_node == (Val)-1) mult_node = push(OP_LOAD_MULT, 0, 0, 0, true); return mult_node; }
     void store_msm(Val a, uint32_t slot) { push(OP_STORE_MSM, a, 0, slot, false); }
@@ -274,6 +276,11 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     if (total_inst > (1u << 20)) { err = "more than 2^20 instance values per proof are not supported by this build"; return H2V_ERR_INSTANCE_TOO_LARGE; }
     for (size_t l : col_lens) if (l > n) { err = "instance column longer than the domain"; return H2V_ERR_INSTANCE_TOO_LARGE; }
     plan.col_lens = col_lens; plan.n_instance_values = (uint32_t)total_inst;
+    {   // H2V_WIDE_INSTANCES overrides the threshold (tests force the kernel path on small circuits with 0)
+        size_t threshold = 1024;
+        if (const char* e = getenv("H2V_WIDE_INSTANCES")) threshold = (size_t)strtoull(e, nullptr, 10);
+        plan.wide_instances = total_inst > threshold;
+    }
 
     const size_t A = vk.num_advice_columns, L = vk.lookups.size(), Sh = vk.shuffles.size(), P = vk.permutation_columns.size();
     const size_t chunk = vk.cs_degree - 2, nsets = P == 0 ? 0 : (P + chunk - 1) / chunk, H = vk.cs_degree - 1;
@@ -413,6 +420,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     std::vector<Val> user_ch(Ch);
     for (size_t i = 0; i < Ch; ++i) user_ch[i] = chal((uint32_t)i);
     Val theta = chal(C_THETA), beta = chal(C_BETA), gamma = chal(C_GAMMA), y = chal(C_Y), x = chal(C_X), sv = chal(C_SV), su = chal(C_SU);
+    plan.x_chal = sq_of[C_X]; plan.domain_k = vk.k; plan.omega = omega; plan.n_inv = n_inv;
     Val sy = gwc ? sv : chal(C_SY);
     Val xn = b.sqrn(x, vk.k);  // x^n, n = 2^k   (lib.rs:180,259)
     Val xn_m1 = b.sub(xn, b.one());
@@ -427,7 +435,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         size_t flat = 0; (void)flat;
         for (const QueryH& q : vk.instance_queries) {
             if (q.column.index >= col_lens.size()) { err = "instance query names a missing column"; return H2V_ERR_FORMAT; }
-            for (size_t j = 0; j < col_lens[q.column.index]; ++j) need_l((int64_t)j - q.rotation);
+            if (!plan.wide_instances) for (size_t j = 0; j < col_lens[q.column.index]; ++j) need_l((int64_t)j - q.rotation);
         }
     }
 
@@ -513,6 +521,11 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         for (size_t c = 1; c < col_lens.size(); ++c) col_base[c] = col_base[c - 1] + (uint32_t)col_lens[c - 1];
         std::map<int64_t, Val> l_cache;
         for (const QueryH& q : vk.instance_queries) {
+            if (plan.wide_instances) {   // evaluated by k_instance_eval before the program runs
+                plan.inst_queries.push_back({col_base[q.column.index], (uint32_t)col_lens[q.column.index], omega_pow(-(int64_t)q.rotation)});
+                instance_evals.push_back(b.load_insteval((uint32_t)plan.inst_queries.size() - 1));
+                continue;
+            }
             Val acc = b.zero();
             for (size_t j = 0; j < col_lens[q.column.index]; ++j) {
                 int64_t r = norm_rot((int64_t)j - q.rotation);

@@ -166,3 +166,37 @@ def test_many_public_inputs():
     assert bad == circuits.oracle_verify_batch(s, P, I2, rand) and bad[0] is False
     assert ctx.verify_each(P, I2) == [0, 0, -2]
     ctx.close(); s.free()
+
+
+def test_instance_kernel_path_equals_program_path(monkeypatch):
+    """Wide instance vectors are evaluated by k_instance_eval instead of being unrolled into the Fr program; the threshold
+    (H2V_WIDE_INSTANCES, read when a plan is compiled) is forced to 0 here so that small circuits take the kernel path too:
+    same challenges, Guard, accumulators and verdicts as the program path and as the oracle, for an odd column length,
+    a tampered input and a lookup circuit."""
+    import random
+    import halo2_verifier_amd as h2v
+    from circuits import R_MOD
+    rnd = random.Random(99)
+    for make, prove in ((lambda: circuits.setup_vector_mul(8, 37), None), (lambda: circuits.setup_wide(8, A=8, F=5, L_=1, Sh=1, deg=3), "wide")):
+        s = make()
+        if prove is None:
+            P, I = circuits.prove_vector_mul_batch(s, 5, seed=3, threads=4)
+        else:
+            pairs = [circuits.prove_wide(s, witness_seed=i) for i in range(3)]
+            P, I = [p for p, _ in pairs], [i for _, i in pairs]
+        I2 = list(I)
+        I2[1] = [[circuits.le32(123)] + I[1][0][1:]]
+        rand = [rnd.randrange(1, R_MOD) for _ in range(len(P))]
+        results = []
+        for env in (None, "0"):
+            if env is None:
+                monkeypatch.delenv("H2V_WIDE_INSTANCES", raising=False)
+            else:
+                monkeypatch.setenv("H2V_WIDE_INSTANCES", env)
+            ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
+            results.append((ctx.verify_batch(P, I, rand), ctx.verify_batch(P, I2, rand), ctx.verify_each(P, I2), ctx.guard_msm(P[0], I[0])))
+            ctx.close()
+        assert results[0] == results[1]
+        assert results[0][0] == circuits.oracle_verify_batch(s, P, I, rand) and results[0][0][0] is True
+        assert results[0][1] == circuits.oracle_verify_batch(s, P, I2, rand)
+        s.free()
