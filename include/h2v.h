@@ -102,7 +102,9 @@ int h2v_pairing_check(h2v_ctx* ctx, const uint8_t left_xy[64], const uint8_t rig
  * rand32: the n scalars that AccumulatorStrategy::process draws with Fr::random
  * (kzg/strategy.rs:129), in call order; NULL = draw from the OS RNG.
  * per_proof_status[i]: 0 or the plonk::Error the reference's verify_proof returns for proof i;
- * a failing proof contributes nothing to the accumulator.
+ * a failing proof contributes nothing to the accumulator.  (An instance value that is not a canonical
+ * field element cannot be expressed in the reference, whose instances are typed Fr; here it is
+ * reported as H2V_ERR_INVALID_INSTANCES for that proof.)
  * batch_ok: all statuses OK and the single pairing check passed.
  * out_left_xy / out_right_xy: the two evaluated channels of the final DualMSM (may be NULL). */
 int h2v_verify_batch(h2v_ctx* ctx, size_t n,
