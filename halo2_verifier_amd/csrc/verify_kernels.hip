@@ -22,7 +22,7 @@ __device__ __forceinline__ void status_set(int* status, uint32_t p, int code) {
     atomicMin(&status[p], code);  // Transcript (-5) outranks Opening (-4): the reference stops at the first failing read
 }
 
-__global__ void __launch_bounds__(64) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
+__global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
                                                    uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, uint8_t* __restrict__ ycanon,
                                                    int* __restrict__ status) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
