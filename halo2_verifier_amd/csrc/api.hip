@@ -54,6 +54,7 @@ int h2v_ctx_create_ex(const uint8_t* params, size_t params_len, int params_forma
 void h2v_ctx_destroy(h2v_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->scratch_batch) { h2v_batch_destroy(ctx->scratch_batch); ctx->scratch_batch = nullptr; }
     ctx->pairing.release();
     ctx->msm_ws.release();
     ctx_release_vk(ctx);

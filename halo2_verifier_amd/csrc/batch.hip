@@ -200,6 +200,22 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     return 0;
 }
 
+// one-shot calls reuse a batch object kept in the context (up to H2V_SCRATCH_BATCH_MAX proofs of capacity)
+#define H2V_SCRATCH_BATCH_MAX 1024u
+int scratch_batch_take(h2v_ctx* ctx, size_t capacity, size_t max_inst, h2v_batch** out) {
+    h2v_batch* b = ctx->scratch_batch;
+    ctx->scratch_batch = nullptr;
+    if (b && (b->max_proofs < capacity || b->max_inst < max_inst)) { h2v_batch_destroy(b); b = nullptr; }
+    if (!b) { int rc = h2v_batch_create(ctx, capacity, max_inst, &b); if (rc) return rc; }
+    *out = b;
+    return 0;
+}
+void scratch_batch_give(h2v_ctx* ctx, h2v_batch* b) {
+    if (!b) return;
+    if (b->max_proofs > H2V_SCRATCH_BATCH_MAX || ctx->scratch_batch) { h2v_batch_destroy(b); return; }
+    ctx->scratch_batch = b;
+}
+
 // pack pointer-array proofs / instances into the flat layout; proofs shorter than the VK's proof are
 // the reader running dry: "failed to fill whole buffer" -> Error::Transcript, or Opening inside the multi-open part
 int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t ncols,
@@ -208,6 +224,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
     if (!ctx || (n && (!proofs || !proof_lens)) || (ncols && !col_lens)) { set_last_error("null argument"); return H2V_ERR_BAD_ARGUMENT; }
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     if (ncols != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
+    std::lock_guard<std::mutex> lock(ctx->mu);   // one one-shot call per context at a time (it owns the context's scratch batch)
     std::vector<size_t> lens(col_lens, col_lens + ncols);
     PlanDevice* pd = nullptr;
     int rc = ctx_get_plan(ctx, lens, &pd);
@@ -233,7 +250,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
         // SingleStrategy (kzg/strategy.rs:143-181) = an accumulator of ONE proof with multiplier 1 and its own pairing: run the
         // proofs as one-proof groups of grouped launches, at most MSM_MAX_PROBLEMS / 2 per launch
         const size_t per = MSM_MAX_PROBLEMS / 2;
-        if ((rc = h2v_batch_create(ctx, std::min(n ? n : 1, per), pl.n_instance_values, &b))) return rc;
+        if ((rc = scratch_batch_take(ctx, std::min(n ? n : 1, per), pl.n_instance_values, &b))) return rc;
         bool all = true;
         for (size_t off = 0; off < n && !rc; off += per) {
             const size_t m = std::min(per, n - off);
@@ -252,10 +269,11 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
             }
         }
         if (batch_ok && !rc) *batch_ok = all ? 1 : 0;
-        h2v_batch_destroy(b);
+        scratch_batch_give(ctx, b);
         return rc;
     }
-    if ((rc = h2v_batch_create(ctx, n ? n : 1, pl.n_instance_values, &b))) return rc;
+    if ((rc = scratch_batch_take(ctx, n ? n : 1, pl.n_instance_values, &b))) return rc;
+    if ((rc = h2v_batch_set_groups(b, 1))) { h2v_batch_destroy(b); return rc; }
     do {
         if ((rc = upload_impl(b, n, flat.data(), pl.proof_len, iflat.data(), ncols, col_lens, rand32, rand32 ? n : 0))) break;
         if ((rc = launch_impl(b, with_pairing))) break;
@@ -266,7 +284,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
         if (per_proof_status) for (size_t i = 0; i < n; ++i) per_proof_status[i] = st[i];
         if (batch_ok) *batch_ok = ok;
     } while (0);
-    if (keep && !rc) *keep = b; else h2v_batch_destroy(b);
+    if (keep && !rc) *keep = b; else scratch_batch_give(ctx, b);
     return rc;
 }
 

@@ -5,6 +5,7 @@
 #include <mutex>
 
 namespace h2v { struct VkDevice; }
+struct h2v_batch;
 
 struct h2v_ctx {
     int device = 0;
@@ -15,6 +16,7 @@ struct h2v_ctx {
     std::mutex mu;                 // serialises the single-shot entry points
     h2v::VkDevice* vk = nullptr;   // per-VK compiled program and constants (vkplan.hip)
     int multiopen = 0, transcript = 0;  // h2v_options
+    struct h2v_batch* scratch_batch = nullptr;  // kept between one-shot calls (h2v_verify_batch / _each): ~20 device allocations saved per call
 };
 
 namespace h2v {

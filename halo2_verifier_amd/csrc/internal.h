@@ -27,7 +27,7 @@ struct MsmPlan {
     uint32_t windows;  // ceil(129 / c): GLV halves are 128-bit magnitudes, +1 bit for the signed-digit carry
     uint32_t buckets;  // 2^(c-1) per window (signed digits)
 };
-MsmPlan msm_plan(uint32_t n);
+MsmPlan msm_plan(uint32_t n, bool latency = false);
 
 // One MSM of a multi-problem launch: term i < n1 reads scalars[i * sstride ..+8) and bases[i * bstride]; terms n1 <= i < n
 // read a second segment (scalars2, bases2) at index i - n1 (a batch's VK-wide bases live apart from its own points).

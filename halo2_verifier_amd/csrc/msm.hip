@@ -50,10 +50,12 @@ namespace h2v {
 // lanes that share a window's bucket reduction: one wave up to 2048 buckets, four beyond
 static inline uint32_t msm_window_threads(uint32_t buckets) { return buckets <= 64 ? std::max(1u, buckets) : (buckets <= 2048 ? 64u : 256u); }
 
-// Window width by a cost model in Fq products: 2n mixed additions (11) per window, and per window the reduction
-// sum_b (b+1) B_b done by T lanes: 2 * slice running-sum additions, a c-bit double-and-add to weight the slice, a log2(T)
-// tree — full additions (16 products), T lanes wide.
-MsmPlan msm_plan(uint32_t n) {
+// Window width.  Throughput plan: a cost model in Fq products — 2n mixed additions (11) per window, and per window the
+// reduction sum_b (b+1) B_b done by T lanes: 2 * slice running-sum additions, a c-bit double-and-add to weight the slice, a
+// log2(T) tree — full additions (16 products), T lanes wide.  Latency plan (a launch whose problems are all tiny, e.g. one
+// proof under SingleStrategy): the work is negligible whatever c is, what counts is the dependent chain — the window
+// reduction's additions and msm_final's one addition per window on top of its ~130 doublings — so fewer, wider windows win.
+MsmPlan msm_plan(uint32_t n, bool latency) {
     MsmPlan best{n, 2, 65, 2};
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 15; ++c) {
@@ -61,19 +63,24 @@ MsmPlan msm_plan(uint32_t n) {
         uint32_t b = 1u << (c - 1);
         uint32_t T = msm_window_threads(b), slice = (b + T - 1) / T;
         double lg = 0; for (uint32_t t = T; t > 1; t >>= 1) lg += 1;
-        double cost = (double)w * (11.0 * 2.0 * n + 16.0 * T * (2.0 * slice + 1.5 * c + 1.0 + lg));
+        double cost = latency ? 9.0 * w + 9.0 * (2.0 * slice + 1.5 * c + 1.0 + lg) + 5.0 * std::min<double>(32.0, 2.0 * n)   // microseconds: final, window, one chunk
+                              : (double)w * (11.0 * 2.0 * n + 16.0 * T * (2.0 * slice + 1.5 * c + 1.0 + lg));
         if (cost < best_cost) { best_cost = cost; best = MsmPlan{n, c, w, b}; }
     }
     return best;
 }
+// a launch is planned for latency when all its problems together are a few thousand terms
+static inline bool msm_latency_bound(size_t total_terms) { return total_terms <= 4096; }
 
 int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_per_problem) {
     release();
     cap_terms = max_terms; cap_problems = max_problems;
     if (!max_per_problem || max_per_problem > max_terms) max_per_problem = max_terms;
     size_t mb = 0;
-    for (uint32_t n = 1; n <= max_per_problem; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n); mb = std::max(mb, (size_t)p.windows * p.buckets); }
-    { MsmPlan p = msm_plan(max_per_problem); mb = std::max(mb, (size_t)p.windows * p.buckets); }
+    for (int lat = 0; lat < 2; ++lat) {
+        for (uint32_t n = 1; n <= max_per_problem; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n, lat != 0); mb = std::max(mb, (size_t)p.windows * p.buckets); }
+        MsmPlan p = msm_plan(max_per_problem, lat != 0); mb = std::max(mb, (size_t)p.windows * p.buckets);
+    }
     mb *= max_problems;
     cap_buckets = mb;
     // list entries: 2 GLV halves x windows per term, for the plan of the largest problem of a launch
@@ -81,7 +88,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     for (uint32_t n = 1;; n = n < 16 ? n + 1 : n + n / 8) {
         if (n > max_per_problem) n = max_per_problem;
         size_t terms = std::min<size_t>(max_terms, (size_t)n * max_problems);
-        cap_list = std::max(cap_list, terms * 2 * msm_plan(n).windows);
+        cap_list = std::max(cap_list, terms * 2 * std::max(msm_plan(n, false).windows, msm_plan(n, true).windows));
         if (n == max_per_problem) break;
     }
     H2V_HIP_CHECK(hipMalloc(&counts, (mb + 2) * 4));
@@ -542,7 +549,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     }
     if (nmax > MSM_ENTRY_TERM) { set_last_error("msm_enqueue_multi: more than 2^30 terms in one problem"); return H2V_ERR_BAD_ARGUMENT; }
     if (total > ws.cap_terms) { set_last_error("msm_enqueue_multi: terms exceed workspace capacity"); return H2V_ERR_BAD_ARGUMENT; }
-    MsmPlan p = msm_plan(nmax);
+    MsmPlan p = msm_plan(nmax, msm_latency_bound(total));
     uint32_t nbq = p.windows * p.buckets, nb = nbq * count;
     if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 2) * 4, s));
