@@ -56,7 +56,7 @@ struct alignas(128) G1JSlot {
 
 struct MsmWorkspace {
     uint32_t cap_terms = 0, cap_problems = 0;
-    uint32_t* counts = nullptr;   // [problems * windows * buckets + 2]  (last two words: number of heavy buckets, list cursor)
+    uint32_t* counts = nullptr;   // [problems * windows * buckets + 3]  (last three words: number of heavy buckets, list cursor, number of straddling buckets)
     uint32_t* offsets = nullptr;  // [problems * windows * buckets]
     uint32_t* cursor = nullptr;   // scatter cursors, then the heavy-bucket list
     uint32_t* list = nullptr;     // term indices sorted by (problem, window, bucket)

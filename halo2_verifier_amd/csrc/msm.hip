@@ -22,9 +22,10 @@
 //                   lanes) and no bucket is ever too big for a lane (the top window of a 254-bit scalar is only a few bits
 //                   wide: its buckets collect hundreds of entries).  A bucket that lies inside one chunk is written
 //                   directly; the head and tail pieces of a chunk go to a side array and
-//      msm_fixup    one lane per bucket sums the pieces of a bucket that straddles chunks (buckets spread over more than
-//                   64 chunks — skewed inputs — go to msm_fixup_heavy, one workgroup each) and writes the identity for
-//                   empty buckets
+//      msm_fixup_classify / msm_fixup
+//                   a lane per bucket writes the identity for empty buckets and lists the buckets that straddle chunks;
+//                   a second, dense launch sums their pieces (buckets spread over more than 64 chunks — skewed inputs —
+//                   go to msm_fixup_heavy, one workgroup each)
 //   5. msm_window   one wave (four for more than 2048 buckets) per (problem, window): sum_b (b+1) * bucket[b] by per-lane
 //                   running sums over a slice of buckets, then a cross-lane butterfly (wave shuffles; LDS tree for four waves)
 //   6. msm_final    one lane per problem: Horner over windows (c doublings + one add per window)
@@ -91,7 +92,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
         cap_list = std::max(cap_list, terms * 2 * std::max(msm_plan(n, false).windows, msm_plan(n, true).windows));
         if (n == max_per_problem) break;
     }
-    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 2) * 4));
+    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 3) * 4));
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&cursor, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
@@ -423,16 +424,27 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
     for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, msm_piece_src(partial, i, i0, off)->p);
     *out = acc;
 }
-// after the scatter `cursor` is free: it becomes the list of heavy buckets, counts[nb] their number
-__global__ void __launch_bounds__(64) msm_fixup(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
-                                                uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
+// After the scatter `cursor` is free and becomes two work lists: buckets that straddle chunks, from the front (their number
+// in counts[nb + 2]), and buckets spread over >= MSM_FIXUP_SERIAL chunks, from the back (counts[nb]).  Classifying first and
+// adding in a second, dense launch keeps the waves of the addition kernel full: only ~40 % of the buckets straddle.
+__global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ lists,
+                                                          G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t cnt = counts[b], off = offsets[b];
     if (cnt == 0) { bucket_pts[b] = G1J::identity(); return; }
     const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
     if (i0 == i1) return;  // written whole by its chunk
-    if (i1 - i0 >= MSM_FIXUP_SERIAL) { heavy[atomicAdd(&counts[nb], 1u)] = b; return; }
+    if (i1 - i0 >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&counts[nb], 1u)] = b;
+    else lists[atomicAdd(&counts[nb + 2], 1u)] = b;
+}
+__global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
+                                                const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= counts[nb + 2]) return;
+    const uint32_t b = lists[k];
+    const uint32_t cnt = counts[b], off = offsets[b];
+    const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
     // in-register additions; pieces of one bucket can coincide or cancel (the same point in two chunks): complete formulas then
     G1J acc = msm_piece_src(partial, i0, i0, off)->p;
     bool ok = true;
@@ -447,7 +459,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
     const uint32_t t = threadIdx.x;
     // every workgroup reaches the exit condition: the heavy list is complete before this kernel starts
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const uint32_t b = heavy[h];
+        const uint32_t b = heavy[nb - 1 - h];
         const uint32_t cnt = counts[b], off = offsets[b];
         const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
         G1J acc = G1J::identity();
@@ -552,7 +564,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     MsmPlan p = msm_plan(nmax, msm_latency_bound(total));
     uint32_t nbq = p.windows * p.buckets, nb = nbq * count;
     if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
-    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 2) * 4, s));
+    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 3) * 4, s));
     const uint32_t tiles = (nmax + MSM_TILE - 1) / MSM_TILE;
     dim3 gt(8 * ((count + 7) / 8) * tiles);
     const uint32_t wpp = std::max<uint32_t>(1u, std::min<uint32_t>(p.windows, MSM_LDS_WORDS / p.buckets));
@@ -567,6 +579,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     const size_t max_entries = total * 2 * p.windows;
     const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK - 1) / MSM_CHUNK);
     hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
+    hipLaunchKernelGGL(msm_fixup_classify, dim3((nb + 255) / 256), dim3(256), 0, s, ws.counts, ws.offsets, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(msm_window_threads(p.buckets)), 0, s, ws.bucket_pts, ws.window_sums, p);
