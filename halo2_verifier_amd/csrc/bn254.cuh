@@ -224,6 +224,32 @@ template <class PR> struct Fp {
         r.v[8] = (uint32_t)acc;
         return r;
     }
+    // A value given as signed per-limb accumulators, V = sum acc[l] * 2^(29 l) with 0 <= V < 2^261 (any integer linear
+    // combination of a few residues, e.g. 9a + (2p - b)), brought to [0, 1.0001p) WITHOUT a Montgomery pass: one carry
+    // sweep, then V - q p with q = floor(top limb / (top limb of p + 1)) — an under-estimate of floor(V / p) by at most
+    // one (the top limbs are 29 and 22 bits: V - q p < p + (q + 1) 2^232), so the result is non-negative and below 2p.
+    // q <= 2^29 / 2^21.6 < 170.  The division is a multiplication by floor(2^40 / d) with one correction step: exact.
+    H2V_HD static Fp from_wide(const int64_t acc[9]) {
+        uint32_t v[9];
+        int64_t carry = 0;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            const int64_t t = acc[l] + carry;
+            if (l < 8) { v[l] = (uint32_t)(t & (int64_t)H2V_LIMB_MASK); carry = t >> 29; } else v[l] = (uint32_t)t;
+        }
+        constexpr uint32_t d = PR::P29(8) + 1;
+        constexpr uint64_t M = (uint64_t(1) << 40) / d;
+        uint32_t q = (uint32_t)(((uint64_t)v[8] * M) >> 40);
+        if (v[8] - q * d >= d) ++q;
+        Fp r;
+        carry = 0;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            const int64_t t = (int64_t)v[l] - (int64_t)q * (int64_t)PR::P29(l) + carry;
+            if (l < 8) { r.v[l] = (uint32_t)(t & (int64_t)H2V_LIMB_MASK); carry = t >> 29; } else r.v[l] = (uint32_t)t;
+        }
+        return r;
+    }
     // (a0*b0 + a1*b1)/R mod p in ONE reduction pass: 27 terms per column still fit the 64-bit accumulator (27 * 2^58 + carry
     // < 2^63).  Representatives < 2p give a result < 1.05p.  This is what makes an Fq2 product two passes and no additions.
     __host__ __device__ __forceinline__ static Fp dot2_inl(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1) {

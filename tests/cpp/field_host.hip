@@ -8,6 +8,9 @@
 #include "../../halo2_verifier_amd/csrc/bn254.cuh"
 using namespace h2v;
 
+template <class F> struct FP29;
+template <> struct FP29<Fq> { static uint32_t limb(int l) { return FqParams::P29(l); } };
+template <> struct FP29<Fr> { static uint32_t limb(int l) { return FrParams::P29(l); } };
 static bool parse(const char* hex, uint32_t raw[8]) {
     if (strlen(hex) != 64) return false;
     for (int w = 0; w < 8; ++w) {
@@ -45,6 +48,13 @@ template <class F> static int run() {
         else if (o == "dot2") print(F::dot2_inl(x, y, z, w));
         else if (o == "chain") {            // (((x*y - x) + y)^2 - y) * x : lazily reduced intermediates feed every kind of operation
             F t = x * y - x; t = t + y; t = t.sqr() - y; print(t * x);
+        } else if (o == "wide") {           // 9x + (2p - y) + 9(2p - z) + w + x + y as ONE integer combination of the limbs, then from_wide
+            int64_t acc[9];
+            for (int l = 0; l < 9; ++l) {
+                const int64_t p2 = 2 * (int64_t)FP29<F>::limb(l);
+                acc[l] = 9 * (int64_t)x.v[l] + (p2 - (int64_t)y.v[l]) + 9 * (p2 - (int64_t)z.v[l]) + (int64_t)w.v[l] + (int64_t)x.v[l] + (int64_t)y.v[l];
+            }
+            print(F::from_wide(acc));
         } else if (o == "eq") printf("%d\n", (x == y) ? 1 : 0);
         else if (o == "iszero") printf("%d\n", (x - y).is_zero() ? 1 : 0);
         else if (o == "mont256") print(F::from_mont256(ra));   // a = residue * 2^256 mod p as words

@@ -38,7 +38,7 @@ def test_field_operations_match_big_integers(exe, field):
     lines, want = [], []
     for _ in range(400):
         a, b, c, d = (rnd.choice(vals) for _ in range(4))
-        op = rnd.choice(["mul", "sqr", "add", "sub", "neg", "dbl", "inv", "dot2", "chain", "eq", "iszero"])
+        op = rnd.choice(["mul", "sqr", "add", "sub", "neg", "dbl", "inv", "dot2", "chain", "eq", "iszero", "wide", "wide"])
         if op == "mul": lines.append(f"mul {h(a)} {h(b)}"); want.append(h(a * b % p))
         elif op == "sqr": lines.append(f"sqr {h(a)}"); want.append(h(a * a % p))
         elif op == "add": lines.append(f"add {h(a)} {h(b)}"); want.append(h((a + b) % p))
@@ -48,8 +48,13 @@ def test_field_operations_match_big_integers(exe, field):
         elif op == "inv": lines.append(f"inv {h(a)}"); want.append(h(pow(a, -1, p) if a else 0))
         elif op == "dot2": lines.append(f"dot2 {h(a)} {h(b)} {h(c)} {h(d)}"); want.append(h((a * b + c * d) % p))
         elif op == "chain": lines.append(f"chain {h(a)} {h(b)}"); want.append(h((((a * b - a) + b) ** 2 - b) * a % p))
+        elif op == "wide": lines.append(f"wide {h(a)} {h(b)} {h(c)} {h(d)}"); want.append(h((9 * a - b - 9 * c + d + a + b) % p))
         elif op == "eq": lines.append(f"eq {h(a)} {h(b)}"); want.append("1" if a == b else "0")
         else: lines.append(f"iszero {h(a)} {h(b)}"); want.append("1" if a == b else "0")
+    # from_wide's quotient estimate takes its correction step about once in 2^11 calls: exercise it a few thousand times
+    for _ in range(4000):
+        a, b, c, d = (rnd.randrange(p) for _ in range(4))
+        lines.append(f"wide {h(a)} {h(b)} {h(c)} {h(d)}"); want.append(h((9 * a - b - 9 * c + d + a + b) % p))
     # halo2curves' in-memory Montgomery words (R = 2^256) -> this representation
     for _ in range(20):
         a = rnd.randrange(p)
