@@ -1,12 +1,12 @@
 // Final pairing check kernel:  e(left, s_g2) * e(right, -g2) == 1  (DualMSM::check,
 // poly/kzg/msm.rs:185-203).
 //
-// One WAVE per check.  A pairing is a strictly sequential chain of ~550 Fq12 products (Miller loop over 6x+2,
-// then the final exponentiation); on a single lane that is ~20 000 dependent Fq products ~ 50 ms, and a batch
-// ends with exactly one of them.  Here an Fq12 element lives in LDS as six Fq2 coefficients of
-// Fq2[w]/(w^6 - xi), and each product is spread over the wave: lane (i, j) of 36 computes a_i * b_j (one Fq2
-// product = 3 Fq products), the 36 partial products go through LDS, and six lanes fold them with the
-// w^6 = xi reduction.  The chain becomes ~550 x (one Fq2 product + a 6-term fold).
+// One WAVE per check.  A pairing is a strictly sequential chain of ~480 Fq12 products (Miller loop over 6x+2,
+// then the final exponentiation); on a single lane that is ~20 000 dependent Fq products, and a batch ends with exactly
+// one of them.  Here an Fq12 element lives in LDS as six Fq2 coefficients of Fq2[w]/(w^6 - xi), and each product is spread
+// over the wave: a lane computes ONE coordinate of one a_i * b_j as a single-pass sum of two Fq products (the factor xi of
+// the pairs with i + j >= 6 is applied to the operand by an integer combination on the limbs), the partial products go
+// through LDS, and twelve lanes add six of them each.  No modular additions, no Karatsuba, no Montgomery pass in the fold.
 //
 // The G2 side is constant per context, so its Miller-loop line coefficients are precomputed once on the host
 // (g2_prepare); the wave evaluates them at the two G1 points up front, all lines in parallel, into LDS.
@@ -31,53 +31,50 @@ struct WaveShared {
     Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6];
 };
 
-// Fq2 product as two sum-of-two-products passes (no Karatsuba additions): c0 = a0*b0 + a1*(-b1), c1 = a0*b1 + a1*b0.
-// Results are < 1.05p each.
-__device__ __noinline__ Fq2 fq2_mul_dot(Fq2 a, Fq2 b) {
-    const Fq nb1 = b.c1.neg();
-    return {Fq::dot2_inl(a.c0, b.c0, a.c1, nb1), Fq::dot2_inl(a.c0, b.c1, a.c1, b.c0)};
-}
-// One Fq coordinate (c = 0: real, 1: imaginary) of coefficient k of  sum_{i+j=k} P_ij + xi * sum_{i+j=k+6} P_ij,  xi = 9 + u,
-// from the 36 partial products: an INTEGER linear combination of up to 11 residues with weights 1, 9 and -1 (as 2p - x),
-// accumulated per limb in 64 bits, carried once, and brought back below 2p by one Montgomery pass with R mod p (the
-// combination is < 64p; a product with a factor < p divides it by R again: < 1.4p).  Replaces ~36 modular additions.
-__device__ __noinline__ Fq wfold_coord(const Fq2* __restrict__ prod, uint32_t k, uint32_t c) {
-    // 32-bit per-limb sums first (six residues of 29-bit limbs cannot overflow): SL = the lo terms' coordinate, SH = the hi
-    // terms' coordinate, OH = the hi terms' other coordinate
-    uint32_t SL[9], SH[9], OH[9];
-#pragma unroll
-    for (int l = 0; l < 9; ++l) { SL[l] = 0; SH[l] = 0; OH[l] = 0; }
-#pragma unroll
-    for (uint32_t i = 0; i < 6; ++i) {
-        const bool lo = i <= k;
-        const Fq2& P = prod[i * 6 + (lo ? k - i : k + 6 - i)];
-        const Fq& same = c ? P.c1 : P.c0;
-        const Fq& other = c ? P.c0 : P.c1;
+// The w^6 = xi = 9 + u reduction is applied to an OPERAND, not to the products: lane (i, j) with i + j >= 6 multiplies a_i by
+// xi * b_j = (9 b0 - b1) + (9 b1 + b0) u, an integer combination of two residues on the limbs brought below 2p by
+// Fp::from_wide (no Montgomery pass), so that every coefficient of the result is a PLAIN sum of six partial products.
+// (Computing xi * b once per product in a phase of its own was tried: the extra barrier costs more than the redundancy.)
+// One coordinate of the Fq2 product a * b (or a * xi b), one reduction pass (Fp::dot2_inl, result < 1.05p):
+//   real      = a0 * B0 + a1 * (-B1)        imaginary = a0 * B1 + a1 * B0        with (B0, B1) = b or xi b
+__device__ __noinline__ Fq fq2_mul_coord(Fq2 a, Fq2 b, uint32_t coord, bool times_xi) {
+    Fq s0, s1;
+    if (!times_xi) {
+        s0 = coord ? b.c1 : b.c0;
+        s1 = coord ? b.c0 : b.c1.neg();
+    } else {
+        // B0 = 9 b0 + (2p - b1);  B1 = 9 b1 + b0;  -B1 = 9 (2p - b1) + (2p - b0).  All positive, < 21p.
+        int64_t t0[9], t1[9];
 #pragma unroll
         for (int l = 0; l < 9; ++l) {
-            const uint32_t x = same.v[l], y = other.v[l];
-            SL[l] += lo ? x : 0u;
-            SH[l] += lo ? 0u : x;
-            OH[l] += lo ? 0u : y;
+            const int64_t p2 = 2 * (int64_t)FqParams::P29(l), b0 = b.c0.v[l], b1 = b.c1.v[l];
+            const int64_t B0 = 9 * b0 + (p2 - b1), B1 = 9 * b1 + b0, nB1 = 9 * (p2 - b1) + (p2 - b0);
+            t0[l] = coord ? B1 : B0;
+            t1[l] = coord ? B0 : nB1;
         }
+        s0 = Fq::from_wide(t0);
+        s1 = Fq::from_wide(t1);
     }
-    // SL + 9 SH + OH (imaginary) or SL + 9 SH + (n_hi * 2p - OH) (real), carried once
-    const int64_t n_hi = 5 - (int64_t)k;
-    Fq v;
-    int64_t carry = 0;
-#pragma unroll
-    for (int l = 0; l < 9; ++l) {
-        int64_t t = (int64_t)SL[l] + (((int64_t)SH[l]) << 3) + (int64_t)SH[l] + carry;
-        t += c ? (int64_t)OH[l] : n_hi * (int64_t)(2u * FqParams::P29(l)) - (int64_t)OH[l];
-        if (l < 8) { v.v[l] = (uint32_t)(t & (int64_t)H2V_LIMB_MASK); carry = t >> 29; } else v.v[l] = (uint32_t)t;   // total < 64p < 2^261
-    }
-    return Fq::mul_inl(v, Fq::one());
-}
-
-// one coordinate of an Fq2 product, one reduction pass: real = a0*b0 + a1*(-b1), imaginary = a0*b1 + a1*b0 (< 1.05p)
-__device__ __noinline__ Fq fq2_mul_coord(Fq2 a, Fq2 b, uint32_t coord) {
-    const Fq s0 = coord ? b.c1 : b.c0, s1 = coord ? b.c0 : b.c1.neg();
     return Fq::dot2_inl(a.c0, s0, a.c1, s1);
+}
+// One Fq coordinate of coefficient k of the product: the sum of the six partial products P_ij with i + j = k (mod 6) — the
+// xi factor already sits in the ones with i + j >= 6 — added on the limbs (six 29-bit limbs cannot overflow 32 bits) and
+// reduced below 2p by Fp::from_wide.
+__device__ __noinline__ Fq wfold_coord(const Fq2* __restrict__ prod, uint32_t k, uint32_t c) {
+    uint32_t sum[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) sum[l] = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+        const Fq2& P = prod[i * 6 + (i <= k ? k - i : k + 6 - i)];
+        const Fq& v = c ? P.c1 : P.c0;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) sum[l] += v.v[l];
+    }
+    int64_t acc[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) acc[l] = (int64_t)sum[l];
+    return Fq::from_wide(acc);
 }
 __device__ __forceinline__ void prod_store(Fq2* prod, uint32_t idx, uint32_t coord, const Fq& v) { if (coord) prod[idx].c1 = v; else prod[idx].c0 = v; }
 __device__ __forceinline__ void wfold(WaveShared& s, Fq2* dst, uint32_t lane) {
@@ -90,7 +87,11 @@ __device__ __forceinline__ void wfold(WaveShared& s, Fq2* dst, uint32_t lane) {
 }
 // dst = x * y in Fq2[w]/(w^6 - xi); dst may alias x or y.  36 lanes, two passes each.
 __device__ __forceinline__ void wmul(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {
-    if (lane < 36) s.prod[lane] = fq2_mul_dot(x[lane / 6], y[lane % 6]);
+    if (lane < 36) {
+        const uint32_t i = lane / 6, j = lane % 6;
+        const Fq2 a = x[i], b = y[j];
+        s.prod[lane] = {fq2_mul_coord(a, b, 0, i + j >= 6), fq2_mul_coord(a, b, 1, i + j >= 6)};
+    }
     wfold(s, dst, lane);
 }
 // dst = x^2: the 21 products a_i*a_j, i <= j, are each computed once — 42 lanes, ONE pass each — and stored at both (i, j) and (j, i)
@@ -101,7 +102,7 @@ __device__ __forceinline__ void wsqr(WaveShared& s, Fq2* dst, const Fq2* x, uint
         uint32_t i = 0, r = pr;
         while (r >= 6 - i) { r -= 6 - i; ++i; }
         const uint32_t j = i + r;
-        const Fq v = fq2_mul_coord(x[i], x[j], coord);
+        const Fq v = fq2_mul_coord(x[i], x[j], coord, i + j >= 6);
         prod_store(s.prod, i * 6 + j, coord, v);
         prod_store(s.prod, j * 6 + i, coord, v);
     }
@@ -111,7 +112,7 @@ __device__ __forceinline__ void wsqr(WaveShared& s, Fq2* dst, const Fq2* x, uint
 __device__ __forceinline__ void wmul_line(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* l, uint32_t lane) {
     if (lane < 60) {
         const uint32_t pr = lane >> 1, coord = lane & 1, i = pr / 5, j = pr % 5;
-        prod_store(s.prod, i * 6 + j, coord, fq2_mul_coord(x[i], l[j], coord));
+        prod_store(s.prod, i * 6 + j, coord, fq2_mul_coord(x[i], l[j], coord, i + j >= 6));
     }
     if (lane < 12) prod_store(s.prod, (lane >> 1) * 6 + 5, lane & 1, Fq::zero());
     wfold(s, dst, lane);
