@@ -125,12 +125,15 @@ __device__ __forceinline__ void wfrob(Fq2* dst, const Fq2* src, const PairingCon
     if (lane < 6) { Fq2 c = src[lane].conj(); dst[lane] = lane == 0 ? c : Fq2::mul(c, k->gamma1[lane]); }
     __syncthreads();
 }
-// tower view: c0 = (a0, a2, a4), c1 = (a1, a3, a5)
-__device__ __noinline__ void winv_lane0(Fq2* dst, const Fq2* src) {
-    Fq12 t;
-    t.c0 = {src[0], src[2], src[4]}; t.c1 = {src[1], src[3], src[5]};
+// Inverse in the tower view f = c0 + c1 w, c0 = (a0, a2, a4), c1 = (a1, a3, a5) in Fq6 = Fq2[v]/(v^3 - xi), w^2 = v:
+// f^-1 = (c0 - c1 w) / N with N = f * (c0 - c1 w) = c0^2 - v c1^2 in Fq6 (only even powers of w).  The two products run on
+// the wave; only the Fq6 inversion (one Fq inversion inside) is left to a single lane.  n must hold N on entry and holds
+// N^-1 (as an element of the big field) on return.
+__device__ __noinline__ void winv6_lane0(Fq2* n) {
+    Fq6 t = {n[0], n[2], n[4]};
     t = t.inv();
-    dst[0] = t.c0.c0; dst[2] = t.c0.c1; dst[4] = t.c0.c2; dst[1] = t.c1.c0; dst[3] = t.c1.c1; dst[5] = t.c1.c2;
+    n[0] = t.c0; n[2] = t.c1; n[4] = t.c2;
+    n[1] = Fq2::zero(); n[3] = Fq2::zero(); n[5] = Fq2::zero();
 }
 // dst = x^BN_X (x in the cyclotomic subgroup); tmp is scratch; dst must not alias x
 __device__ __forceinline__ void wpow_x(WaveShared& s, Fq2* dst, const Fq2* x, uint32_t lane) {
@@ -184,9 +187,11 @@ __global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pai
     wmul_line(s, s.f, s.f, s.line[idx++], lane);
     wmul_line(s, s.f, s.f, s.line[idx++], lane);
     // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
-    if (lane == 0) winv_lane0(s.t0, s.f);
+    wconj(s.t1, s.f, lane);                    // t1 = conj(f) = f^(p^6)
+    wmul(s, s.t2, s.f, s.t1, lane);            // N = f * conj(f), in Fq6
+    if (lane == 0) winv6_lane0(s.t2);
     __syncthreads();
-    wconj(s.t1, s.f, lane);
+    wmul(s, s.t0, s.t1, s.t2, lane);           // f^-1
     wmul(s, s.r, s.t1, s.t0, lane);            // f^(p^6 - 1)
     wfrob(s.t0, s.r, consts, lane);
     wfrob(s.t0, s.t0, consts, lane);
