@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <array>
 #include <set>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -760,6 +761,14 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     for (uint32_t s2 = 0; s2 < np; ++s2) if (left_scalar[s2] != (Val)-1) b.store_left(b.mul(left_scalar[s2], mult), s2);
 
     b.emit(plan.code, plan.n_slots);
+    if (getenv("H2V_DUMP_PLAN")) {   // diagnostic: size and instruction mix of the compiled Fr program
+        std::map<uint32_t, size_t> hist;
+        for (const VmInstr& in : plan.code) ++hist[in.op];
+        fprintf(stderr, "[h2v plan] %zu instructions, %u slots, %zu constants, %zu stream bytes, %u points, %u shared bases; ops:", plan.code.size(), plan.n_slots,
+                b.consts.size(), plan.stream.size(), plan.n_points, plan.n_shared);
+        for (auto& kv : hist) fprintf(stderr, " %u:%zu", kv.first, kv.second);
+        fprintf(stderr, "\n");
+    }
     plan.consts = b.consts;
     // LOAD_CHAL immediates already refer to squeeze order
     return 0;
