@@ -123,3 +123,51 @@ def test_g1_group_law_including_degenerate_cases(curve_exe):
     assert len(got) == len(want)
     for l, g, w in zip(lines, got, want):
         assert g == w, l
+
+
+# ---------------------------------------------------------------- the Fq12 tower on the host
+def _tower_to_flat(c):
+    """[c0.c0.c0, c0.c0.c1, c0.c1.c0, ...] (Fq6 c0 = coefficients of w^0, w^2, w^4; c1 = w^1, w^3, w^5; u = w^6 - 9)
+    -> coefficients of w^0..w^11 in Fq[w]/(w^12 - 18 w^6 + 82)."""
+    flat = [0] * 12
+    for half in range(2):
+        for j in range(3):
+            k = 2 * j + half                       # power of w carried by this Fq2 coefficient
+            a0, a1 = c[half * 6 + 2 * j], c[half * 6 + 2 * j + 1]
+            flat[k] = (flat[k] + a0 - 9 * a1) % PQ
+            flat[k + 6] = (flat[k + 6] + a1) % PQ
+    return flat
+
+
+def _flat_to_tower(flat):
+    c = [0] * 12
+    for half in range(2):
+        for j in range(3):
+            k = 2 * j + half
+            c[half * 6 + 2 * j + 1] = flat[k + 6] % PQ
+            c[half * 6 + 2 * j] = (flat[k] + 9 * flat[k + 6]) % PQ
+    return c
+
+
+def test_fq12_tower_matches_the_flat_python_field(tmp_path_factory):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyref
+    out = tmp_path_factory.mktemp("tower") / "tower_host"
+    r = subprocess.run(["hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-o", str(out), os.path.join(ROOT, "tests", "cpp", "tower_host.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rnd = random.Random(12)
+    h = lambda x: "%064x" % x
+    lines, want = [], []
+    for _ in range(12):
+        a = [rnd.randrange(PQ) for _ in range(12)]
+        b = [rnd.randrange(PQ) for _ in range(12)]
+        lines.append("mul " + " ".join(h(x) for x in a + b))
+        want.append(_flat_to_tower(pyref.f12_mul(_tower_to_flat(a), _tower_to_flat(b))))
+        lines.append("inv " + " ".join(h(x) for x in a))
+        want.append(_flat_to_tower(pyref.f12_inv(_tower_to_flat(a))))
+    r = subprocess.run([str(out)], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = [[int(x, 16) for x in l.split()] for l in r.stdout.strip().split("\n")]
+    assert got == want
