@@ -477,49 +477,61 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
     }
 }
 
+// The out-of-line group law with explicit destinations: operands are loaded from wherever they live (LDS here), the
+// result is stored where the caller says — no hidden return-value temporaries in scratch memory.
+__device__ __noinline__ void g1_add_to(G1J* dst, const G1J* a, const G1J* b) { const G1J x = *a, y = *b; *dst = g1_add_inl(x, y); }
+__device__ __noinline__ void g1_dbl_to(G1J* dst, const G1J* a) { const G1J x = *a; *dst = g1_dbl_inl(x); }
+
 // A lone wave per window is latency-bound, and the two inlined additions of the running-sum step are ~70 KB of code —
 // more than the instruction cache, so every iteration streamed its code from L2 (measured 2x the time of the arithmetic).
-// Here the group law is the shared out-of-line routine (one 35 KB body, complete formulas): the accumulators live in
-// memory across the calls, which costs a 108-byte load/store against a ~9 us addition.
+// Here the group law is the shared out-of-line routine (one 35 KB body, complete formulas) and the three accumulators of a
+// lane live in LDS (dynamic: 3 x T points, + T for the four-wave tree): kept in private memory across the calls they cost
+// 0.35 GB of scratch write-backs per launch.
 __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ window_sums, MsmPlan p) {
-    __shared__ G1J red[MSM_WIN_THREADS];
+    extern __shared__ G1J win_lds[];
     const uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x, T = blockDim.x;   // T: a power of two (msm_window_threads)
+    G1J* run = win_lds + t;
+    G1J* sum = win_lds + T + t;
+    G1J* scaled = win_lds + 2 * T + t;
+    G1J* red = win_lds + 3 * T;           // only allocated when T > 64
     const uint32_t slice = (p.buckets + T - 1) / T;
     const uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
-    G1J run = G1J::identity(), sum = G1J::identity();
+    *run = G1J::identity(); *sum = G1J::identity();
     const G1JSlot* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
     for (uint32_t b = hi; b > lo; --b) {
-        run = g1_add(run, bp[b - 1]);
-        sum = g1_add(sum, run);
+        g1_add_to(run, run, &bp[b - 1].p);
+        g1_add_to(sum, sum, run);
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
     if (lo < hi && lo > 0) {
-        G1J scaled = G1J::identity();
+        *scaled = G1J::identity();
         for (int i = (int)p.c - 1; i >= 0; --i) {
-            scaled = g1_dbl(scaled);
-            if ((lo >> i) & 1) scaled = g1_add(scaled, run);
+            g1_dbl_to(scaled, scaled);
+            if ((lo >> i) & 1) g1_add_to(scaled, scaled, run);
         }
-        sum = g1_add(sum, scaled);
+        g1_add_to(sum, sum, scaled);
     }
     if (T <= 64) {
-        // a single wave: butterfly over the lanes with cross-lane moves (27 dwords per step), no LDS and no barrier;
+        // a single wave: butterfly over the lanes with cross-lane moves (27 dwords per step), no barrier;
         // lanes beyond T hold the identity
         for (uint32_t d = 32; d > 0; d >>= 1) {
+            const G1J mine = *sum;
             G1J other;
             uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&sum);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&mine);
 #pragma unroll
             for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 64);
             if (t + d >= T) other = G1J::identity();
-            sum = g1_add(sum, other);
+            *scaled = other;
+            g1_add_to(sum, sum, scaled);
         }
-        if (t == 0) window_sums[(size_t)q * p.windows + w] = sum;
+        if (t == 0) window_sums[(size_t)q * p.windows + w] = *sum;
         return;
     }
-    red[t] = sum;
+    red[t] = *sum;
     __syncthreads();
     for (uint32_t d = T / 2; d > 0; d >>= 1) {
-        if (t < d) red[t] = g1_add(red[t], red[t + d]);
+        if (t < d) g1_add_to(&red[t], &red[t], &red[t + d]);
         __syncthreads();
     }
     if (t == 0) window_sums[(size_t)q * p.windows + w] = red[0];
@@ -584,7 +596,12 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_fixup_classify, dim3((nb + 255) / 256), dim3(256), 0, s, ws.counts, ws.offsets, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
-    hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(msm_window_threads(p.buckets)), 0, s, ws.bucket_pts, ws.window_sums, p);
+    {
+        const uint32_t T = msm_window_threads(p.buckets);
+        const size_t win_lds = (size_t)(T > 64 ? 4 : 3) * T * sizeof(G1J);   // 20 KB for one wave, 108 KB for four
+        if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
+        hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(T), win_lds, s, ws.bucket_pts, ws.window_sums, p);
+    }
     hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
