@@ -16,9 +16,12 @@
  *     (VerifyingKey::write  halo2_verifier/src/plonk/vk.rs:41-64;
  *      ParamsKZG::write_custom  halo2_verifier/src/poly/kzg/commitment.rs:142-152).
  *   - serde format codes follow helpers.rs:7-19: 0 Processed, 1 RawBytes, 2 RawBytesUnchecked.
- *   - Threading: a context is immutable after creation and may be shared between host
- *     threads; a batch object owns one HIP stream and its device workspace and must be used
- *     from one thread at a time.  Several batches may be in flight on one context.
+ *   - Threading: a context may be shared between host threads: its VK / params / compiled plans are
+ *     immutable after creation, and the one-shot entry points (h2v_verify_batch, h2v_verify_each,
+ *     h2v_guard_msm, h2v_msm_g1, h2v_pairing_check, h2v_fold_check) serialise themselves on an internal
+ *     lock (they share the context's stream and a cached workspace).  A batch object owns one HIP stream
+ *     and its device workspace and must be used from one thread at a time; several batches may be in
+ *     flight on one context.
  */
 #ifndef H2V_H
 #define H2V_H
