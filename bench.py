@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: proofs verified / second (BN254, k = 14) on N MI355X of one node.
 
-One "step" = one pass of the whole hot path (point decompression -> Blake2b transcript -> Fr program
--> shared-base fold -> pooled MSMs -> one pairing) over one batch of `--batch` proofs PER GPU that is
-already resident in HBM.  N > 1: every rank verifies its own shard, the 2 accumulator points per rank
-are all-gathered over RCCL and folded, and a single pairing closes the whole N x batch step (weak scaling).
-The tail of a step — window Horner, the pairing — is a handful of waves with millisecond-long dependent chains, so
-steps are issued `--groups` at a time as one grouped batch (h2v_batch_set_groups: every kernel runs once for all of
-them, each step keeps its own accumulators and its own pairing) and `--depth` such launches are in flight (one HIP
-stream each); all K timed steps start and finish inside the timed region.
+One "step" = one pass of the whole hot path (point decompression -> Blake2b transcript -> Fr program -> shared-base fold
+-> pooled MSMs -> one pairing) over one batch of `--batch` proofs PER GPU that is already resident in HBM.  N > 1: every
+rank verifies its own shard, one 224-byte accumulator record per rank and step (2 G1 points + the shard's failed-proof
+count) is all-gathered over RCCL and folded, and a single pairing closes the whole N x batch step (weak scaling).
+The tail of a step — window Horner, the pairing — is a handful of waves with long dependent chains, so steps are issued
+`--groups` at a time as one grouped batch (h2v_batch_set_groups: every kernel runs once for all of them, each step keeps
+its own accumulators and its own pairing) and `--depth` such launches are in flight (one HIP stream each); all K timed
+steps start and finish inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the MSM stage (the kernel BASELINE.json names):
-achieved = 96 B x terms / mean MSM-stage time measured with HIP events on the batch's own stream.
-`cpu_baseline` = the CPU oracle (a port of the reference algorithm, single thread like the reference)
-timed on a bounded sample of the same proofs on this host.
+`python bench.py --gpus N` started as a plain process launches the N ranks itself (halo2_verifier_amd/launch.py: N fresh
+child processes, the parent never touches the GPU); under torch.distributed.run the ranks come from the environment.  Either
+way WORLD_SIZE must equal --gpus, otherwise the run fails instead of silently measuring another job.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the MSM stage (the kernel BASELINE.json names): achieved = 96 B x terms /
+mean MSM-stage time measured with HIP events on the batch's own stream; `roofline.kernels` breaks out msm_accumulate.
+`cpu_baseline` = the CPU oracle (a port of the reference algorithm, single thread like the reference) timed on a bounded
+sample of the same proofs on this host.
 """
 import argparse
-import math
 import ctypes
+import datetime
 import json
 import os
 import sys
@@ -27,14 +31,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# A batch's tail (window Horner, pairing) is one or two waves; throughput comes from many batches in flight, each on
-# its own HIP stream.  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), which
-# would serialise most of them; ask for 16 before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 K_CIRCUIT = 14
 N_PUBLIC = 8
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MAX_HW_QUEUES = 16      # see hw_queue_env()
+
+
+def hw_queue_env():
+    """A batch's tail (window Horner, pairing) is one or two waves; throughput comes from several launches in flight, each on
+    its own HIP stream.  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), which would
+    serialise most of them; ask for 16 before the runtime initialises.  More is not better (24 measured slower) and the
+    runtime aborts at 32 on this stack, so an inherited larger value is clamped, not trusted."""
+    try:
+        v = int(os.environ.get("GPU_MAX_HW_QUEUES", MAX_HW_QUEUES))
+    except ValueError:
+        v = MAX_HW_QUEUES
+    os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(v, MAX_HW_QUEUES)))
 
 
 def load_or_make_proofs(count, k, log):
@@ -55,8 +67,9 @@ def load_or_make_proofs(count, k, log):
     d = dict(proofs=b"".join(P), inst=b"".join(b"".join(col) for inst in I for col in inst), vk=s.vk, params=s.params)
     s.free()
     for x, p in paths.items():
-        with open(p, "wb") as f:
+        with open(p + ".tmp", "wb") as f:
             f.write(d[x])
+        os.replace(p + ".tmp", p)
     log(f"generated {count} proofs (k={k}) with {threads} threads in {time.time() - t:.1f}s")
     return d
 
@@ -109,218 +122,328 @@ def cpu_baseline(d, sample, log):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
-    ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--groups", type=int, default=32, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups)")
-    ap.add_argument("--depth", type=int, default=8, help="launches in flight per GPU (one HIP stream each)")
-    ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
-    ap.add_argument("--cpu-sample", type=int, default=2048)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reupload", action="store_true", help="copy the host buffers to the device again before every launch (the PCIe-inclusive rate quoted in DESIGN.md; never the default)")
-    args = ap.parse_args()
+def launch_shape(steps, groups, depth):
+    """How K steps are cut into launches.  groups / depth = 0 -> automatic: a launch's latency chain (transcript -> Fr program ->
+    MSM tail -> pairing) is several milliseconds whatever it carries, so a short run is spread over several launches in flight
+    (their chains overlap) and a long one fills every launch (fewer, larger kernels)."""
+    if depth <= 0:
+        depth = 8
+    if groups <= 0:
+        groups = max(1, min(32, (steps + depth - 1) // depth))
+    groups = max(1, min(groups, steps))
+    launches, rem = steps // groups, steps % groups
+    depth = max(1, min(depth, launches))
+    return groups, launches, rem, depth
 
+
+def traffic_record(terms_per_launch):
+    """HBM traffic of the MSM stage per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot be taken
+    inside the timed region).  The record of this launch shape if there is one, otherwise the nearest shape scaled per term."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_msm_traffic*.json"))):
+        try:
+            tj = json.load(open(path))
+            t, b = tj["terms_per_launch"], tj["msm_stage_traffic_bytes_per_launch"]
+        except Exception:
+            continue
+        if not t or not b:
+            continue
+        key = (abs(t - terms_per_launch), -os.path.getmtime(path))
+        if best is None or key < best[0]:
+            best = (key, path, t, b, tj)
+    if best is None:
+        return None, "no PMC profile committed", None
+    _, path, t, b, tj = best
+    rel = os.path.relpath(path, ROOT)
+    if t == terms_per_launch:
+        return b, f"{rel} (same launch shape: {t} terms per launch; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes)", tj
+    return b * terms_per_launch / t, f"{rel} scaled per term ({t} -> {terms_per_launch} terms per launch; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes)", tj
+
+
+def rank_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     log = (lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if rank == 0 else (lambda m: None)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different job than the one asked for "
+                         f"(start it as `python bench.py --gpus {args.gpus}` or under torch.distributed.run with --nproc-per-node {args.gpus})")
+    one_device = os.environ.get("H2V_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("H2V_BENCH_BACKEND", "nccl")
 
+    if args.dry_run:
+        # the launch plan, no GPU: what the N ranks would do, plus a rendezvous + collective over gloo to prove the job is N ranks
+        import torch
+        import torch.distributed as dist
+        from halo2_verifier_amd import distributed as h2d
+        G, launches, rem, depth = launch_shape(args.steps, args.groups, args.depth)
+        total = args.batch * world
+        lo, hi = h2d.shard_bounds(total, world, rank)
+        seen = world
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        print(f"[bench] dry run: rank {rank}/{world} local_rank {local_rank} shard [{lo}, {hi}) of {total} proofs per step", file=sys.stderr, flush=True)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "steps_per_launch": G,
+                              "launches": launches, "remainder_steps": rem, "pipeline_depth": depth, "proofs_per_gpu_per_step": args.batch}), flush=True)
+        return
+
+    hw_queue_env()
     import torch
     import torch.distributed as dist
     import halo2_verifier_amd as h2v
     from halo2_verifier_amd import distributed as h2d
 
-    if not torch.cuda.is_available() or h2v.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    need = 1 if one_device else (local_rank + 1 if world == 1 else world)
+    if not torch.cuda.is_available() or h2v.device_count() < need:
+        raise SystemExit(f"bench.py needs {need} HIP device(s) for --gpus {args.gpus} (found {h2v.device_count()}): the product path has no CPU fallback")
     # rehearsal knobs (not used by the driver): H2V_BENCH_BACKEND=gloo and H2V_BENCH_ONE_DEVICE=1 run an N-rank job on a
     # single-GPU box (all ranks on cuda:0, collectives staged through the host) to exercise the multi-rank control flow
-    backend = os.environ.get("H2V_BENCH_BACKEND", "nccl")
-    if os.environ.get("H2V_BENCH_ONE_DEVICE") == "1":
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+
+    def barrier():
+        if world > 1:
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     # inputs: rank 0 generates (or loads) the proofs, the others wait and read the cache
     if rank == 0:
         d = load_or_make_proofs(args.distinct, K_CIRCUIT, log)
-    if world > 1:
-        dist.barrier()
+    barrier()
     if rank != 0:
         d = load_or_make_proofs(args.distinct, K_CIRCUIT, log)
 
-    # A step is one batch of B proofs per GPU with its own accumulators and its own pairing (AccumulatorStrategy).  One launch
-    # carries G steps side by side (a grouped batch): every kernel runs once for all G, each group keeps its own verdict.
-    B = args.batch
-    # EXACTLY --steps timed steps: `launches` launches of G steps, plus one launch of the remaining `rem` steps (own object)
-    G = max(1, min(args.groups, args.steps))
-    launches, rem = args.steps // G, args.steps % G
-    warm_launches = (args.warmup + G - 1) // G
-    reps = (B + args.distinct - 1) // args.distinct
-    proofs_one = (d["proofs"] * reps)[: B * 1024]
-    inst_one = (d["inst"] * reps)[: B * 32 * N_PUBLIC]
-    total = B * world
-    lo, hi = h2d.shard_bounds(total, world, rank)
-    # per group one seeded stream of Fr::random draws for the whole (N x batch) step, indexed by global proof id; a rank
-    # uploads, for every group, the draws from its first proof to the end of the step (the multiplier of a proof is the
-    # product of the draws of all later proofs of its step)
-    tails = []
-    for g in range(G):
-        rand_all = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567 + g * 0x51ed27) % (1 << 250)).to_bytes(32, "little") for i in range(1, total + 1))
-        tails.append(h2d.tail_for_shard(rand_all, lo))
-
     ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes), device=local_rank)
     shape = ctx.proof_shape()
-    depth = max(1, min(args.depth, launches))
-    # objects 0 .. depth-1 carry G steps each; object `depth` (if any) carries the `rem` steps that complete --steps
-    sizes = [G] * depth + ([rem] if rem else [])
-    streams = [torch.cuda.Stream(device=local_rank) for _ in sizes]
-    batches = []
-    for s, g in zip(streams, sizes):
-        b = h2v.Batch(ctx, B * g, N_PUBLIC, stream=s.cuda_stream, groups=g)
-        b.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
-        b.set_profiling(True)
-        batches.append(b)
-    acc_local = [torch.empty(h2d.ACC_BYTES * g, dtype=torch.uint8, device=f"cuda:{local_rank}") for g in sizes]
-    gathered = [None] * len(sizes)
-    in_flight = [False] * len(sizes)
-    stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
-    stage_cnt = 0
-    results = []
 
-    def retire(i, timed):
-        nonlocal stage_cnt
-        ok, st, left, right = batches[i].finish_groups()
-        in_flight[i] = False
-        if not all(ok) or any(st):
-            raise SystemExit(f"verification failed inside the benchmark: ok={ok}")
-        if timed and i < depth:   # stage statistics are per full launch
-            for k2, v in batches[i].timings_ms().items():
-                stage_sum[k2] += v
-            stage_cnt += 1
-        results.append((left, right))
+    def measure(B, steps, warmup, groups, depth_arg, reupload=False, isolated_launches=0):
+        """Time exactly `steps` steps of B proofs per GPU.  A step is one batch of B proofs per GPU with its own accumulators
+        and its own pairing (AccumulatorStrategy).  One launch carries G steps side by side (a grouped batch); `depth` launches
+        are in flight; a remainder launch completes --steps.  Returns a dict of timings."""
+        G, launches, rem, depth = launch_shape(steps, groups, depth_arg)
+        warm_launches = (warmup + G - 1) // G
+        reps = (B + args.distinct - 1) // args.distinct
+        proofs_one = (d["proofs"] * reps)[: B * 1024]
+        inst_one = (d["inst"] * reps)[: B * 32 * N_PUBLIC]
+        total = B * world
+        lo, hi = h2d.shard_bounds(total, world, rank)
+        # per group one seeded stream of Fr::random draws for the whole (N x batch) step, indexed by global proof id; a rank
+        # uploads, for every group, the draws from its first proof to the end of the step (the multiplier of a proof is the
+        # product of the draws of all later proofs of its step)
+        tails = []
+        for g in range(G):
+            rand_all = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567 + g * 0x51ed27) % (1 << 250)).to_bytes(32, "little") for i in range(1, total + 1))
+            tails.append(h2d.tail_for_shard(rand_all, lo))
+        # objects 0 .. depth-1 carry G steps each; object `depth` (if any) carries the `rem` steps that complete --steps
+        sizes = [G] * depth + ([rem] if rem else [])
+        streams = [torch.cuda.Stream(device=local_rank) for _ in sizes]
+        batches = []
+        for s, g in zip(streams, sizes):
+            b = h2v.Batch(ctx, B * g, N_PUBLIC, stream=s.cuda_stream, groups=g)
+            b.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
+            b.set_profiling(True)
+            batches.append(b)
+        acc_local = [torch.empty(h2d.ACC_BYTES * g, dtype=torch.uint8, device=dev) for g in sizes]
+        gathered = [None] * len(sizes)
+        in_flight = [False] * len(sizes)
+        stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
+        stage_cnt = [0]
+        uploads = [(proofs_one * g, inst_one * g, b"".join(tails[:g])) for g in sizes] if reupload else None
 
-    uploads = [(proofs_one * g, inst_one * g, b"".join(tails[:g])) for g in sizes] if args.reupload else None
+        def retire(i, timed):
+            ok, st, left, right = batches[i].finish_groups()
+            in_flight[i] = False
+            if not all(ok) or any(st):
+                raise SystemExit(f"verification failed inside the benchmark: ok={ok}")
+            if timed and i < depth:   # stage statistics are per full launch
+                for k2, v in batches[i].timings_ms().items():
+                    stage_sum[k2] += v
+                stage_cnt[0] += 1
 
-    def submit(i):
-        b = batches[i]
-        if uploads:
-            b.upload(uploads[i][0], 1024, uploads[i][1], [N_PUBLIC], uploads[i][2])
-        if world == 1:
-            b.launch(with_pairing=True)
-        else:
-            with torch.cuda.stream(streams[i]):
-                b.launch(with_pairing=False)
-                b.export_accumulators(acc_local[i].data_ptr())
-                gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 216 B per rank
-                b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
-        in_flight[i] = True
+        def submit(i):
+            b = batches[i]
+            if uploads:
+                b.upload(uploads[i][0], 1024, uploads[i][1], [N_PUBLIC], uploads[i][2])
+            if world == 1:
+                b.launch(with_pairing=True)
+            else:
+                with torch.cuda.stream(streams[i]):
+                    b.launch(with_pairing=False)
+                    b.export_accumulators(acc_local[i].data_ptr())
+                    gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 224 B per rank
+                    b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
+            in_flight[i] = True
 
-    def run(n_launches, timed):
-        for step in range(n_launches):
-            i = step % depth
-            if in_flight[i]:
-                retire(i, timed)
-            submit(i)
-        if rem:
-            submit(depth)
-        for i in range(len(sizes)):
-            if in_flight[i]:
-                retire(i, timed)
+        def run(n_launches, timed, with_rem):
+            for step in range(n_launches):
+                i = step % depth
+                if in_flight[i]:
+                    retire(i, timed)
+                submit(i)
+            if rem and with_rem:
+                submit(depth)
+            for i in range(len(sizes)):
+                if in_flight[i]:
+                    retire(i, timed)
 
-    run(warm_launches, False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(launches, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    # Outside the timed region: a few launches with ONE launch in flight, so that the HIP-event stage times are those of
-    # the kernels alone (with `depth` launches in flight a stage's elapsed time includes other streams' kernels).  The
-    # roofline figure uses these undisturbed durations; they agree with the rocprofv3 depth-1 summary under profiles/.
-    pipelined = dict(stage_sum), stage_cnt
-    stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
-    stage_cnt = 0
-    if world == 1:
-        for _ in range(4):
-            submit(0)
-            retire(0, True)
-    isolated = {k2: v / max(stage_cnt, 1) for k2, v in stage_sum.items()}
-    stage_sum, stage_cnt = pipelined
-
-    if rank == 0:
-        stages = {k2: v / max(stage_cnt, 1) for k2, v in stage_sum.items()}
+        run(warm_launches, False, True)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(launches, True, True)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        stages = {k2: v / max(stage_cnt[0], 1) for k2, v in stage_sum.items()}
+        # Outside the timed region: a few launches with ONE launch in flight, so that the HIP-event stage times are those of
+        # the kernels alone (with several launches in flight a stage's elapsed time includes other streams' kernels).  The
+        # roofline figure uses these undisturbed durations; they agree with the rocprofv3 depth-1 summary under profiles/.
+        isolated = None
+        if isolated_launches:
+            for k2 in stage_sum:
+                stage_sum[k2] = 0.0
+            stage_cnt[0] = 0
+            for _ in range(isolated_launches):
+                submit(0)
+                retire(0, True)
+            isolated = {k2: v / max(stage_cnt[0], 1) for k2, v in stage_sum.items()}
+        for b in batches:
+            b.close()
         n_local = hi - lo
+        n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
         # terms of one launch: every point slot of every local proof (right channel) + the VK-wide bases folded
         # over the batch (fixed + permutation commitments + g) + one h2 term per proof (left channel)
-        n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
-        terms_total = G * (n_local * shape["n_points"] + n_shared + n_local)
-        msm_ms = isolated["msm"] if world == 1 else stages["msm"]
-        # HBM traffic of the MSM stage per launch comes from the committed PMC profile of this same workload
-        # (separate rocprofv3 --pmc passes cannot run inside the timed region); null if it does not match this shape
-        traffic = None
+        terms_launch = G * (n_local * shape["n_points"] + n_shared + n_local)
+        return dict(dt=dt, G=G, launches=launches, rem=rem, depth=depth, total=total, stages=stages, isolated=isolated, terms_launch=terms_launch, B=B)
+
+    m = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=args.reupload, isolated_launches=4 if world == 1 else 0)
+    m_re = None
+    if world == 1 and not args.reupload and not args.no_reupload_leg:
+        # PCIe-inclusive leg (SURVEY.md §8d timing method): the same K steps with the host buffers copied to the device again
+        # before every launch; reported as value_reupload beside `value`, never instead of it
+        m_re = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=True)
+    m_c3 = None
+    if world > 1 and not args.no_config3:
+        # BASELINE.json configs 3 and 5: 8192 proofs per GPU per step (65 536 over 8 GPUs), ONE pairing for the whole N x 8192
+        # step.  Measured after the headline so that `value` keeps the per-GPU shape of the N = 1 run (weak scaling).
+        m_c3 = measure(8192, args.config3_steps, 2, 2, 2)
+
+    if rank == 0:
+        G, depth, B = m["G"], m["depth"], m["B"]
+        stages, isolated = m["stages"], m["isolated"]
+        terms_total = m["terms_launch"]
+        src = isolated if isolated else stages
+        msm_ms = src["msm"]
+        traffic, traffic_src, tj = traffic_record(terms_total)
+        achieved = (96.0 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
+        acc_ms = src.get("msm_accumulate", 0.0)
+        valu = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_msm_traffic.json")))
-            if tj.get("terms_per_launch") == terms_total:
-                traffic = tj["msm_stage_traffic_bytes_per_launch"]
+            valu = (tj or {}).get("valu_active", {}).get("h2v::msm_accumulate")
         except Exception:
             pass
-        achieved = (96.0 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0
+        kernels = {"msm_accumulate": {"ms": acc_ms, "alg_GBps": (96.0 * terms_total) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None,
+                                      "valu_active": valu, "valu_active_source": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the committed --pmc pass named in traffic_source"}}
+        workload = (f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
+                    f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step" + (f" for all {world} x {B} proofs" if world > 1 else "") + f"), {args.distinct} distinct proofs; "
+                    f"{G} steps per launch (grouped batch), {depth} launches in flight" + (f", + one launch of {m['rem']} steps" if m["rem"] else ""))
         out = {
             "metric": "proofs verified/sec (BN254, k=14)",
-            "value": total * args.steps / dt,
+            "value": m["total"] * args.steps / m["dt"],
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": m["dt"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 limbs (254-bit prime-field integers)",
             "data": "synthetic",
-            "config": {"workload": f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
-                                   f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step), {args.distinct} distinct proofs; "
-                                   f"{G} steps per launch (grouped batch), {depth} launches in flight",
+            "config": {"workload": workload,
                        "inputs": "copied host -> device before every launch (PCIe-inclusive)" if args.reupload else "resident in HBM before the timed region",
                        "proofs_per_gpu_per_step": B, "steps_per_launch": G, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "MSM stage (msm_count, prefix sum, msm_scatter, msm_accumulate, msm_fixup, msm_window, msm_final; both channels of every step of a launch)", "terms_per_launch": terms_total,
-                         "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if world == 1 else "HIP events, pipelined",
+                         "algorithmic_bytes_per_launch": 96 * terms_total,
+                         "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if isolated else "HIP events on the launch's stream, inside the timed region (other launches in flight)",
+                         "mean_stage_ms_timed_region": stages["msm"],
+                         "kernels": kernels,
                          "alu": {"note": "the stage is bound by 32-bit integer multiply issue, not by HBM: achieved Fq products/s of the stage against the "
                                          "measured chip-wide peak of the Montgomery product (tools/limb29_microbench.hip)",
                                  "fq_products_per_term": 2 * 12 * 11, "fq_products_per_term_note": "2 GLV halves x 12 windows (c = 11, the 1024-proof step) x 11 per mixed addition",
                                  "achieved_Gprod_s": (2 * 12 * 11 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0,
                                  "peak_Gprod_s": 168.0}},
             "stages_ms": stages,
-            "stages_ms_one_launch_in_flight": isolated if world == 1 else None,
+            "stages_ms_one_launch_in_flight": isolated,
         }
+        if m_re:
+            out["value_reupload"] = m_re["total"] * args.steps / m_re["dt"]
+            out["value_reupload_note"] = "same K steps, host buffers (proofs, instances, draws) copied to the device again before every launch: PCIe-inclusive"
+        if m_c3:
+            out["config3"] = {"workload": f"BASELINE.json configs 3/5: {8192 * world} proofs per step over {world} GPUs (8192 per GPU), one pairing per step after the RCCL all-gather; "
+                                          f"{m_c3['G']} steps per launch, {m_c3['depth']} launches in flight, {args.config3_steps} steps timed",
+                              "value": m_c3["total"] * args.config3_steps / m_c3["dt"], "unit": "proofs/s", "ms_per_step": m_c3["dt"] / args.config3_steps * 1e3,
+                              "proofs_per_step": m_c3["total"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline({**d, "proofs": (d["proofs"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 1024],
                                                 "inst": (d["inst"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 32 * N_PUBLIC]},
                                                args.cpu_sample, log)
         print(json.dumps(out), flush=True)
-    for b in batches:
-        b.close()
     ctx.close()
     if world > 1:
+        barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
+    ap.add_argument("--groups", type=int, default=0, help="steps (independent batches, one pairing each) carried by one launch (h2v_batch_set_groups); 0 = choose from --steps")
+    ap.add_argument("--depth", type=int, default=0, help="launches in flight per GPU (one HIP stream each); 0 = 8")
+    ap.add_argument("--distinct", type=int, default=1024, help="distinct proofs generated (cycled if --batch is larger)")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reupload", action="store_true", help="copy the host buffers to the device again before every launch inside the headline run itself")
+    ap.add_argument("--no-reupload-leg", action="store_true", help="skip the extra PCIe-inclusive leg (value_reupload)")
+    ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the extra 8192-proofs-per-GPU leg (BASELINE.json configs 3/5)")
+    ap.add_argument("--config3-steps", type=int, default=8)
+    ap.add_argument("--dry-run", action="store_true", help="print the launch plan (and, for N > 1, prove the N-rank rendezvous over gloo) without touching the GPU")
+    args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("bench.py: --gpus and --steps must be >= 1, --warmup >= 0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process only launches the N ranks (it imports neither torch nor the HIP library)
+        from halo2_verifier_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    rank_main(args)
 
 
 if __name__ == "__main__":

@@ -34,6 +34,7 @@ SIGNATURES = {
     "h2v_msm_g1": (c_int, [c_vp, c_u8p, c_u8p, c_sz, c_u8p, c_intp]),
     "h2v_pairing_check": (c_int, [c_vp, c_u8p, c_u8p, c_intp]),
     "h2v_verify_batch": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_u8p, c_intp, c_intp, c_u8p, c_u8p]),
+    "h2v_verify_batch_shapes": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_u8p, c_intp, c_intp, c_u8p, c_u8p]),
     "h2v_verify_each": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_intp]),
     "h2v_guard_msm": (c_int, [c_vp, c_u8p, c_sz, c_u8p, c_sz, c_szp, c_u8p, c_u8p, c_szp, c_u8p, c_u8p, c_szp, c_u8p, c_szp]),
     "h2v_batch_create": (c_int, [c_vp, c_sz, c_sz, ctypes.POINTER(c_vp)]),

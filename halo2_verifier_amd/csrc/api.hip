@@ -68,30 +68,34 @@ int h2v_msm_g1(h2v_ctx* ctx, const uint8_t* scalars32, const uint8_t* bases64, s
     std::lock_guard<std::mutex> lock(ctx->mu);
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    uint32_t nn = (uint32_t)n;
-    if (nn > ctx->msm_ws.cap_terms) { int rc = ctx->msm_ws.alloc(nn < 1024 ? 1024 : nn, 1); if (rc) return rc; }
-    uint8_t *d_sb = nullptr, *d_bb = nullptr, *d_out = nullptr; uint32_t *d_s = nullptr, *d_flags = nullptr; G1A* d_b = nullptr; G1J* d_res = nullptr;
-    size_t n1 = n ? n : 1;
-    H2V_HIP_CHECK(hipMalloc(&d_sb, 32 * n1)); H2V_HIP_CHECK(hipMalloc(&d_bb, 64 * n1));
-    H2V_HIP_CHECK(hipMalloc(&d_s, 32 * n1)); H2V_HIP_CHECK(hipMalloc(&d_b, sizeof(G1A) * n1));
-    H2V_HIP_CHECK(hipMalloc(&d_flags, 8 * n1 + 8)); H2V_HIP_CHECK(hipMalloc(&d_res, sizeof(G1J))); H2V_HIP_CHECK(hipMalloc(&d_out, 64));
-    int rc = 0;
-    std::vector<uint32_t> flags(2 * n1 + 1);
-    do {
-        if (n) {
-            if (hipMemcpyAsync(d_sb, scalars32, 32 * n, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(d_bb, bases64, 64 * n, hipMemcpyHostToDevice, s) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
-            if ((rc = scalars_from_bytes_enqueue(s, d_sb, d_s, d_flags, nn))) break;
-            if ((rc = bases_from_bytes_enqueue(s, d_bb, d_b, d_flags + n, nn))) break;
-        }
-        if ((rc = msm_enqueue(s, ctx->msm_ws, d_s, d_b, nn, d_res))) break;
-        if ((rc = point_to_bytes_enqueue(s, d_res, d_out, d_flags + 2 * n, 1))) break;
-        if (hipMemcpyAsync(flags.data(), d_flags, 4 * (2 * n + 1), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(out_xy, d_out, 64, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
-        if (hipStreamSynchronize(s) != hipSuccess) { set_last_error(std::string("h2v_msm_g1: ") + hipGetErrorString(hipGetLastError())); rc = H2V_ERR_DEVICE; break; }
-        for (size_t i = 0; i < 2 * n; ++i) if (flags[i]) { set_last_error(i < n ? "h2v_msm_g1: scalar not canonical" : "h2v_msm_g1: base not on the curve"); rc = H2V_ERR_BAD_ARGUMENT; break; }
-        if (out_is_identity) *out_is_identity = (int)flags[2 * n];
-    } while (0);
-    hipFree(d_sb); hipFree(d_bb); hipFree(d_s); hipFree(d_b); hipFree(d_flags); hipFree(d_res); hipFree(d_out);
-    return rc;
+    const uint32_t nn = (uint32_t)n;
+    int rc;
+    // staging buffers and the Pippenger workspace are kept in the context and only grow (seven hipMalloc / hipFree pairs per
+    // call before); they are owned by the context, so no return path below can leak them
+    OneShotMsm& w = ctx->one_shot;
+    if (nn > w.cap || !w.res.p) {
+        const size_t cap = nn < 1024 ? 1024 : nn;
+        w.cap = 0;
+        if ((rc = w.sb.alloc(32 * cap)) || (rc = w.bb.alloc(64 * cap)) || (rc = w.s.alloc(8 * cap)) || (rc = w.b.alloc(cap)) || (rc = w.flags.alloc(2 * cap + 2)) ||
+            (rc = w.res.alloc(1)) || (rc = w.out.alloc(64))) return rc;
+        if ((rc = ctx->msm_ws.alloc((uint32_t)cap, 1))) return rc;
+        w.cap = (uint32_t)cap;
+    }
+    std::vector<uint32_t> flags(2 * n + 1);
+    if (n) {
+        H2V_HIP_CHECK(hipMemcpyAsync(w.sb.p, scalars32, 32 * n, hipMemcpyHostToDevice, s));
+        H2V_HIP_CHECK(hipMemcpyAsync(w.bb.p, bases64, 64 * n, hipMemcpyHostToDevice, s));
+        if ((rc = scalars_from_bytes_enqueue(s, w.sb.p, w.s.p, w.flags.p, nn))) return rc;
+        if ((rc = bases_from_bytes_enqueue(s, w.bb.p, w.b.p, w.flags.p + n, nn))) return rc;
+    }
+    if ((rc = msm_enqueue(s, ctx->msm_ws, w.s.p, w.b.p, nn, w.res.p))) return rc;
+    if ((rc = point_to_bytes_enqueue(s, w.res.p, w.out.p, w.flags.p + 2 * n, 1))) return rc;
+    H2V_HIP_CHECK(hipMemcpyAsync(flags.data(), w.flags.p, 4 * (2 * n + 1), hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipMemcpyAsync(out_xy, w.out.p, 64, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < 2 * n; ++i) if (flags[i]) { set_last_error(i < n ? "h2v_msm_g1: scalar not canonical" : "h2v_msm_g1: base not on the curve"); return H2V_ERR_BAD_ARGUMENT; }
+    if (out_is_identity) *out_is_identity = (int)flags[2 * n];
+    return 0;
 }
 
 int h2v_pairing_check(h2v_ctx* ctx, const uint8_t left_xy[64], const uint8_t right_xy[64], int* ok) {
@@ -99,23 +103,20 @@ int h2v_pairing_check(h2v_ctx* ctx, const uint8_t left_xy[64], const uint8_t rig
     std::lock_guard<std::mutex> lock(ctx->mu);
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    uint8_t* d_bytes = nullptr; G1A* d_aff = nullptr; uint32_t* d_flags = nullptr; G1J* d_pairs = nullptr;
-    H2V_HIP_CHECK(hipMalloc(&d_bytes, 128)); H2V_HIP_CHECK(hipMalloc(&d_aff, 2 * sizeof(G1A)));
-    H2V_HIP_CHECK(hipMalloc(&d_flags, 16)); H2V_HIP_CHECK(hipMalloc(&d_pairs, 2 * sizeof(G1J)));
-    int rc = 0; uint32_t flags[3] = {0, 0, 0};
-    do {
-        uint8_t host[128]; memcpy(host, left_xy, 64); memcpy(host + 64, right_xy, 64);
-        if (hipMemcpyAsync(d_bytes, host, 128, hipMemcpyHostToDevice, s) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
-        if ((rc = bases_from_bytes_enqueue(s, d_bytes, d_aff, d_flags, 2))) break;
-        if ((rc = affine_to_jacobian_enqueue(s, d_aff, d_pairs, 2))) break;
-        if ((rc = pairing_check_enqueue(s, ctx->pairing, d_pairs, 1, d_flags + 2))) break;
-        if (hipMemcpyAsync(flags, d_flags, 12, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
-        if (hipStreamSynchronize(s) != hipSuccess) { set_last_error(std::string("h2v_pairing_check: ") + hipGetErrorString(hipGetLastError())); rc = H2V_ERR_DEVICE; break; }
-        if (flags[0] || flags[1]) { set_last_error("h2v_pairing_check: point not on the curve"); rc = H2V_ERR_BAD_ARGUMENT; break; }
-        *ok = (int)flags[2];
-    } while (0);
-    hipFree(d_bytes); hipFree(d_aff); hipFree(d_flags); hipFree(d_pairs);
-    return rc;
+    DevBuf<uint8_t> d_bytes; DevBuf<G1A> d_aff; DevBuf<uint32_t> d_flags; DevBuf<G1J> d_pairs;   // freed on every return path
+    int rc;
+    if ((rc = d_bytes.alloc(128)) || (rc = d_aff.alloc(2)) || (rc = d_flags.alloc(4)) || (rc = d_pairs.alloc(2))) return rc;
+    uint32_t flags[3] = {0, 0, 0};
+    uint8_t host[128]; memcpy(host, left_xy, 64); memcpy(host + 64, right_xy, 64);
+    H2V_HIP_CHECK(hipMemcpyAsync(d_bytes.p, host, 128, hipMemcpyHostToDevice, s));
+    if ((rc = bases_from_bytes_enqueue(s, d_bytes.p, d_aff.p, d_flags.p, 2))) return rc;
+    if ((rc = affine_to_jacobian_enqueue(s, d_aff.p, d_pairs.p, 2))) return rc;
+    if ((rc = pairing_check_enqueue(s, ctx->pairing, d_pairs.p, 1, d_flags.p + 2))) return rc;
+    H2V_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, 12, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipStreamSynchronize(s));
+    if (flags[0] || flags[1]) { set_last_error("h2v_pairing_check: point not on the curve"); return H2V_ERR_BAD_ARGUMENT; }
+    *ok = (int)flags[2];
+    return 0;
 }
 
 }  // extern "C"

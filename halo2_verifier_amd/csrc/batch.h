@@ -5,6 +5,28 @@
 
 namespace h2v {
 
+// Per-proof status words on the device.  The reference stops at the FIRST failing step of verify_proof, so when several
+// kernels (or several lanes of one) find different faults in one proof the earliest step of the reference's sequence must
+// win, whatever order the lanes run in: instance values are typed Fr before the call (lib.rs:33-49), then the main transcript
+// reads (Error::Transcript, lib.rs:91-253), then the inversions of the evaluation part (the reference panics: vanishing.rs:100,
+// domain.rs:187-212), then the multi-open reads (Error::Opening, lib.rs:420-424).  Every writer uses atomicMin on these
+// rank-coded values; the host translates them back to the ABI's codes (status_decode).
+#define H2V_DEV_ST_INVALID_INSTANCES (-40)
+#define H2V_DEV_ST_TRANSCRIPT (-30)
+#define H2V_DEV_ST_PANIC (-20)
+#define H2V_DEV_ST_OPENING (-10)
+__device__ __forceinline__ void status_set(int* status, uint32_t p, int dev_code) { atomicMin(&status[p], dev_code); }
+inline int status_decode(int dev) {
+    switch (dev) {
+        case 0: return 0;
+        case H2V_DEV_ST_INVALID_INSTANCES: return H2V_ERR_INVALID_INSTANCES;
+        case H2V_DEV_ST_TRANSCRIPT: return H2V_ERR_TRANSCRIPT;
+        case H2V_DEV_ST_PANIC: return H2V_ERR_REFERENCE_PANIC;
+        case H2V_DEV_ST_OPENING: return H2V_ERR_OPENING;
+        default: return dev;
+    }
+}
+
 struct FrvmArgs {
     const VmInstr* code; uint32_t n_code;
     const Fr* consts;
@@ -45,6 +67,8 @@ int decompress_stage_enqueue(hipStream_t s, const StageArgs& g);
 int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
 // groups > 1: group g owns proofs [g*n/groups, ..) and the draws tail[g*n_tail/groups, ..)
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult);
+// out[i] = src[idx[i]]: the multipliers of a non-contiguous subset of a larger accumulation
+int gather_multipliers_enqueue(hipStream_t s, const Fr* d_src, const uint32_t* d_idx, uint32_t n, Fr* d_out);
 int frvm_enqueue(hipStream_t s, const FrvmArgs& a);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal);
 }  // namespace h2v
@@ -57,6 +81,7 @@ struct h2v_batch {
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
     uint32_t n = 0, n_tail = 0;
     uint32_t groups = 1;              // independent accumulator batches inside this launch (h2v_batch_set_groups)
+    const h2v::Fr* ext_mult = nullptr; const uint32_t* ext_idx = nullptr;   // multipliers gathered from a larger sequence (h2v_verify_batch_shapes)
     bool launched = false, with_pairing = false;
     // device buffers (sized for max_proofs with the plan of the first upload; re-allocated if a later plan needs more)
     uint8_t* proofs = nullptr; uint8_t* inst = nullptr; uint8_t* tail = nullptr;
@@ -67,11 +92,12 @@ struct h2v_batch {
     h2v::G1J* acc = nullptr;      // per group: [2g] left, [2g+1] right
     uint32_t* ok = nullptr;       // [groups]
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
+    uint32_t* fold_failed = nullptr;  // [groups] failed proofs reported by the folded shards (h2v_batch_fold_check_enqueue)
     h2v::MsmWorkspace ws;
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
     uint32_t stream_words = 0;
     // profiling
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
-    float last_ms[6] = {0, 0, 0, 0, 0, 0};
+    float last_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 };

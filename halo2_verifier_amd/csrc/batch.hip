@@ -43,6 +43,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->ok, G))) return rc;
     if ((rc = dev_alloc(b->out_bytes, 128 * G))) return rc;
     if ((rc = dev_alloc(b->out_ident, 2 * G))) return rc;
+    if ((rc = dev_alloc(b->fold_failed, G))) return rc;
     if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + G * pl.n_shared)), (uint32_t)(2 * G), (uint32_t)((N + G - 1) / G * pl.n_points + pl.n_shared)))) return rc;
     b->cap_plan_sig = sig;
     return 0;
@@ -118,6 +119,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     const uint32_t G = b->groups, gs = n / G;
     b->with_pairing = with_pairing != 0; b->launched = true;
     int rc;
+    H2V_HIP_CHECK(hipMemsetAsync(b->fold_failed, 0, 4 * (size_t)G, s));   // set by h2v_batch_fold_check_enqueue only
     int ev = 0;
     auto mark = [&]() { if (b->profiling) hipEventRecord(b->ev[ev], s); ++ev; };
     mark();
@@ -126,7 +128,12 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     if ((rc = decompress_stage_enqueue(s, g))) return rc;
     mark();
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
-    if (n) { if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, G, b->mult))) return rc; }
+    if (n) {
+        // multipliers: suffix products of the uploaded draws — or, for a batch that is a non-contiguous subset of a larger
+        // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
+        if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(s, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
+        else if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, G, b->mult))) return rc;
+    }
     mark();
     if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
@@ -156,6 +163,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
             pr.p.push_back(MsmProblem(b->msm_scal + first * 8, b->pts + first, b->acc + 2 * g + 1, 8, 1, gs * np,
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
         }
+        b->ws.profile = b->profiling; b->ws.profile_recorded = false;
         if ((rc = msm_enqueue_multi(s, b->ws, pr))) return rc;
     }
     mark();
@@ -172,11 +180,12 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     hipStream_t s = b->stream;
     const uint32_t n = b->n, G = b->groups, gs = n / G;
     std::vector<int> st(n ? n : 1, 0);
-    std::vector<uint32_t> okv(G, 1);
+    std::vector<uint32_t> okv(G, 1), foldf(G, 0);
     std::vector<uint8_t> outb(128 * (size_t)G, 0);
     if (n) H2V_HIP_CHECK(hipMemcpyAsync(st.data(), b->status, sizeof(int) * n, hipMemcpyDeviceToHost, s));
     if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
     H2V_HIP_CHECK(hipMemcpyAsync(outb.data(), b->out_bytes, 128 * (size_t)G, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipMemcpyAsync(foldf.data(), b->fold_failed, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_last_error(std::string("h2v_batch_finish: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
     if (b->profiling) {
@@ -185,15 +194,19 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
         hipEventElapsedTime(&t01, b->ev[0], b->ev[1]); hipEventElapsedTime(&t12, b->ev[1], b->ev[2]); hipEventElapsedTime(&t23, b->ev[2], b->ev[3]);
         hipEventElapsedTime(&t34, b->ev[3], b->ev[4]); hipEventElapsedTime(&t45, b->ev[4], b->ev[5]); hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
         b->last_ms[0] = t01; b->last_ms[1] = t12; b->last_ms[2] = t23; b->last_ms[3] = t34; b->last_ms[4] = t45; b->last_ms[5] = t56;
+        float tacc = 0;
+        if (b->ws.profile_recorded) hipEventElapsedTime(&tacc, b->ws.ev_acc[0], b->ws.ev_acc[1]);
+        b->last_ms[6] = tacc;
     }
     std::vector<char> all_ok(G, 1);
     for (uint32_t i = 0; i < n; ++i) {
-        int v = st[i];
+        int v = status_decode(st[i]);
         if (per_proof_status) per_proof_status[i] = v;
         if (v != 0) all_ok[i / gs] = 0;
     }
     for (uint32_t g = 0; g < G; ++g) {
-        if (group_ok) group_ok[g] = (all_ok[g] && (!b->with_pairing || okv[g])) ? 1 : 0;
+        // a sharded group is accepted only if no shard reported a failed proof (their terms are zeroed out of the accumulators)
+        if (group_ok) group_ok[g] = (all_ok[g] && !foldf[g] && (!b->with_pairing || okv[g])) ? 1 : 0;
         if (out_left) memcpy(out_left + 64 * (size_t)g, &outb[128 * (size_t)g], 64);
         if (out_right) memcpy(out_right + 64 * (size_t)g, &outb[128 * (size_t)g + 64], 64);
     }
@@ -218,6 +231,25 @@ void scratch_batch_give(h2v_ctx* ctx, h2v_batch* b) {
 
 // pack pointer-array proofs / instances into the flat layout; proofs shorter than the VK's proof are
 // the reader running dry: "failed to fill whole buffer" -> Error::Transcript, or Opening inside the multi-open part
+int pack_inputs(const Plan& pl, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32,
+                std::vector<uint8_t>& flat, std::vector<uint8_t>& iflat, std::vector<int>& forced) {
+    const size_t per_inst = (size_t)pl.n_instance_values * 32;
+    flat.assign(n * pl.proof_len, 0); iflat.assign(n * per_inst, 0); forced.assign(n, 0);
+    // byte offset where the multi-open part starts: h1 is the first point after all scalars
+    size_t opening_at = pl.opening_offset;
+    for (size_t i = 0; i < n; ++i) {
+        if (!proofs[i]) { set_last_error("null proof pointer"); return H2V_ERR_BAD_ARGUMENT; }
+        if (proof_lens[i] < pl.proof_len) {
+            // the reader runs dry; every point of the packed copy is made undecodable (x = 2^254-1 >= p) so that the proof
+            // contributes nothing, and the status is set to what the reference reports for the place where it ran dry
+            forced[i] = proof_lens[i] < opening_at ? H2V_ERR_TRANSCRIPT : H2V_ERR_OPENING;
+            memset(&flat[i * pl.proof_len], 0xff, pl.proof_len);
+        } else memcpy(&flat[i * pl.proof_len], proofs[i], pl.proof_len);
+        if (per_inst) { if (!instances32 || !instances32[i]) { set_last_error("null instances pointer"); return H2V_ERR_BAD_ARGUMENT; } memcpy(&iflat[i * per_inst], instances32[i], per_inst); }
+    }
+    return 0;
+}
+
 int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t ncols,
                  const size_t* col_lens, const uint8_t* rand32, bool single, int with_pairing, int* per_proof_status, int* batch_ok, uint8_t* out_left,
                  uint8_t* out_right, h2v_batch** keep) {
@@ -231,20 +263,9 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
     if (rc) return rc;
     const Plan& pl = pd->host;
     size_t per_inst = (size_t)pl.n_instance_values * 32;
-    std::vector<uint8_t> flat(n * pl.proof_len, 0), iflat(n * per_inst, 0);
-    std::vector<int> forced(n, 0);
-    // byte offset where the multi-open part starts: h1 is the first point after all scalars
-    size_t opening_at = pl.opening_offset;
-    for (size_t i = 0; i < n; ++i) {
-        if (!proofs[i]) { set_last_error("null proof pointer"); return H2V_ERR_BAD_ARGUMENT; }
-        if (proof_lens[i] < pl.proof_len) {
-            // the reader runs dry; every point of the packed copy is made undecodable (x = 2^254-1 >= p) so that the proof
-            // contributes nothing, and the status is set to what the reference reports for the place where it ran dry
-            forced[i] = proof_lens[i] < opening_at ? H2V_ERR_TRANSCRIPT : H2V_ERR_OPENING;
-            memset(&flat[i * pl.proof_len], 0xff, pl.proof_len);
-        } else memcpy(&flat[i * pl.proof_len], proofs[i], pl.proof_len);
-        if (per_inst) { if (!instances32 || !instances32[i]) { set_last_error("null instances pointer"); return H2V_ERR_BAD_ARGUMENT; } memcpy(&iflat[i * per_inst], instances32[i], per_inst); }
-    }
+    std::vector<uint8_t> flat, iflat;
+    std::vector<int> forced;
+    if ((rc = pack_inputs(pl, n, proofs, proof_lens, instances32, flat, iflat, forced))) return rc;
     h2v_batch* b = nullptr;
     if (single) {
         // SingleStrategy (kzg/strategy.rs:143-181) = an accumulator of ONE proof with multiplier 1 and its own pairing: run the
@@ -325,7 +346,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
     hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->acc); hipFree(b->ok);
-    hipFree(b->out_bytes); hipFree(b->out_ident);
+    hipFree(b->out_bytes); hipFree(b->out_ident); hipFree(b->fold_failed);
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     if (b->stream && b->owns_stream) hipStreamDestroy(b->stream);
@@ -354,7 +375,7 @@ int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, 
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes) {
     if (!b || !b->acc || !device_ptr) { set_last_error("h2v_batch_accumulators: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
     *device_ptr = b->acc;
-    if (nbytes) *nbytes = 2 * sizeof(G1J) * b->groups;
+    if (nbytes) *nbytes = 2 * sizeof(G1J) * b->groups;   // raw points, no failure word: see h2v_batch_export_accumulators
     return 0;
 }
 void* h2v_batch_stream(h2v_batch* b) { return b ? (void*)b->stream : nullptr; }
@@ -369,15 +390,14 @@ int h2v_batch_set_stream(h2v_batch* b, void* hip_stream) {
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst) {
     if (!b || !b->launched || !device_dst) { set_last_error("h2v_batch_export_accumulators: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
-    H2V_HIP_CHECK(hipMemcpyAsync(device_dst, b->acc, 2 * sizeof(G1J) * b->groups, hipMemcpyDeviceToDevice, b->stream));
-    return 0;
+    return export_records_enqueue(b->stream, b->acc, b->status, b->n, b->groups, device_dst);
 }
 int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts) {
     if (!b || !b->launched || !device_accumulators || !n_parts) { set_last_error("h2v_batch_fold_check_enqueue: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     int rc;
     const uint32_t G = b->groups;
-    if ((rc = fold_pairs_enqueue(b->stream, (const G1J*)device_accumulators, (uint32_t)n_parts, b->acc, 2 * G))) return rc;
+    if ((rc = fold_records_enqueue(b->stream, device_accumulators, (uint32_t)n_parts, G, b->acc, b->fold_failed))) return rc;
     if ((rc = pairing_check_enqueue(b->stream, b->ctx->pairing, b->acc, G, b->ok))) return rc;
     if ((rc = point_to_bytes_enqueue(b->stream, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
     b->with_pairing = true;
@@ -386,7 +406,7 @@ int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, 
 int h2v_batch_set_profiling(h2v_batch* b, int enabled) { if (!b) return H2V_ERR_BAD_ARGUMENT; b->profiling = enabled != 0; return 0; }
 int h2v_batch_timings(h2v_batch* b, float* ms, int cap) {
     if (!b || !ms) return H2V_ERR_BAD_ARGUMENT;
-    int k = cap < 6 ? cap : 6;
+    int k = cap < 7 ? cap : 7;
     for (int i = 0; i < k; ++i) ms[i] = b->last_ms[i];
     return k;
 }
@@ -396,27 +416,102 @@ int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts
     std::lock_guard<std::mutex> lock(ctx->mu);
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    G1J* acc = nullptr; uint32_t* d_ok = nullptr; uint8_t* d_out = nullptr; uint32_t* d_ident = nullptr;
-    H2V_HIP_CHECK(hipMalloc(&acc, 2 * sizeof(G1J))); H2V_HIP_CHECK(hipMalloc(&d_ok, 4)); H2V_HIP_CHECK(hipMalloc(&d_out, 128)); H2V_HIP_CHECK(hipMalloc(&d_ident, 8));
-    int rc = 0; uint32_t okv = 0; uint8_t outb[128];
-    do {
-        if ((rc = fold_pairs_enqueue(s, (const G1J*)device_accumulators, (uint32_t)n_parts, acc))) break;
-        if ((rc = pairing_check_enqueue(s, ctx->pairing, acc, 1, d_ok))) break;
-        if ((rc = point_to_bytes_enqueue(s, acc, d_out, d_ident, 2))) break;
-        if (hipMemcpyAsync(&okv, d_ok, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(outb, d_out, 128, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
-        hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { set_last_error(std::string("h2v_fold_check: ") + hipGetErrorString(e)); rc = H2V_ERR_DEVICE; break; }
-        *ok = (int)okv;
-        if (out_left_xy) memcpy(out_left_xy, outb, 64);
-        if (out_right_xy) memcpy(out_right_xy, outb + 64, 64);
-    } while (0);
-    hipFree(acc); hipFree(d_ok); hipFree(d_out); hipFree(d_ident);
-    return rc;
+    DevBuf<G1J> acc; DevBuf<uint32_t> d_ok, d_ident, d_failed; DevBuf<uint8_t> d_out;   // freed on every return path
+    int rc;
+    if ((rc = acc.alloc(2)) || (rc = d_ok.alloc(1)) || (rc = d_out.alloc(128)) || (rc = d_ident.alloc(2)) || (rc = d_failed.alloc(1))) return rc;
+    uint32_t okv = 0, failed = 0; uint8_t outb[128];
+    if ((rc = fold_records_enqueue(s, device_accumulators, (uint32_t)n_parts, 1, acc.p, d_failed.p))) return rc;
+    if ((rc = pairing_check_enqueue(s, ctx->pairing, acc.p, 1, d_ok.p))) return rc;
+    if ((rc = point_to_bytes_enqueue(s, acc.p, d_out.p, d_ident.p, 2))) return rc;
+    H2V_HIP_CHECK(hipMemcpyAsync(&okv, d_ok.p, 4, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipMemcpyAsync(&failed, d_failed.p, 4, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipMemcpyAsync(outb, d_out.p, 128, hipMemcpyDeviceToHost, s));
+    H2V_HIP_CHECK(hipStreamSynchronize(s));
+    *ok = (okv && !failed) ? 1 : 0;
+    if (out_left_xy) memcpy(out_left_xy, outb, 64);
+    if (out_right_xy) memcpy(out_right_xy, outb + 64, 64);
+    return 0;
 }
 
 int h2v_verify_batch(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,
                      const size_t* col_lens, const uint8_t* rand32, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
     return pack_and_run(ctx, n, proofs, proof_lens, instances32, n_instance_columns, col_lens, rand32, false, 1, per_proof_status, batch_ok, out_left_xy, out_right_xy, nullptr);
+}
+
+// N x verify_proof with per-proof instance shapes (lib.rs:33-49 takes `instances` per call): proofs are grouped by shape
+// (one compiled plan each), every group runs as its own batch without a pairing, and the groups' accumulator records are
+// folded into the single pairing.  The multiplier of proof i is the product of the draws of ALL later proofs in call order
+// (kzg/strategy.rs:129, msm.rs:173-176), whatever group they fall in: the suffix products are computed once over the whole
+// sequence and every group gathers its own.
+int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32,
+                            size_t n_instance_columns, const size_t* col_lens_per_proof, const uint8_t* rand32, int* per_proof_status, int* batch_ok,
+                            uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    if (!ctx || (n && (!proofs || !proof_lens)) || (n && n_instance_columns && !col_lens_per_proof)) { set_last_error("h2v_verify_batch_shapes: null argument"); return H2V_ERR_BAD_ARGUMENT; }
+    if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
+    if (n_instance_columns != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
+    const size_t nc = n_instance_columns;
+    std::vector<std::pair<std::vector<size_t>, std::vector<size_t>>> groups;   // (shape, proof indices) in first-appearance order
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<size_t> shape(col_lens_per_proof + i * nc, col_lens_per_proof + (i + 1) * nc);
+        bool found = false;
+        for (auto& g : groups) if (g.first == shape) { g.second.push_back(i); found = true; break; }
+        if (!found) groups.push_back({shape, {i}});
+    }
+    if (groups.size() <= 1)
+        return h2v_verify_batch(ctx, n, proofs, proof_lens, instances32, nc, n ? col_lens_per_proof : nullptr, rand32, per_proof_status, batch_ok, out_left_xy, out_right_xy);
+    std::vector<uint8_t> os_rand;
+    int rc;
+    if (!rand32) { if ((rc = os_random_scalars(os_rand, n))) return rc; rand32 = os_rand.data(); }
+    for (size_t i = 0; i < n; ++i) if (!scalar_is_canonical(rand32 + 32 * i)) { set_last_error("h2v_verify_batch_shapes: rand32 scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; }
+    H2V_HIP_CHECK(hipSetDevice(ctx->device));
+    // whole-sequence multipliers on the context's stream
+    DevBuf<uint8_t> d_rand; DevBuf<Fr> d_mult; DevBuf<uint8_t> d_records; DevBuf<uint32_t> d_idx;
+    if ((rc = d_rand.alloc(32 * n)) || (rc = d_mult.alloc(n)) || (rc = d_records.alloc(H2V_ACC_RECORD_BYTES * groups.size())) || (rc = d_idx.alloc(n))) return rc;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        H2V_HIP_CHECK(hipMemcpyAsync(d_rand.p, rand32, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = multipliers_enqueue(ctx->stream, d_rand.p, (uint32_t)n, (uint32_t)n, 1, d_mult.p))) return rc;
+        H2V_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    bool all_ok = true;
+    size_t idx_off = 0;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const std::vector<size_t>& idx = groups[gi].second;
+        const size_t m = idx.size();
+        PlanDevice* pd = nullptr;
+        if ((rc = ctx_get_plan(ctx, groups[gi].first, &pd))) return rc;
+        const Plan& pl = pd->host;
+        std::vector<const uint8_t*> pp(m), ip(m); std::vector<size_t> plen(m);
+        for (size_t j = 0; j < m; ++j) { pp[j] = proofs[idx[j]]; plen[j] = proof_lens[idx[j]]; ip[j] = instances32 ? instances32[idx[j]] : nullptr; }
+        std::vector<uint8_t> flat, iflat; std::vector<int> forced;
+        if ((rc = pack_inputs(pl, m, pp.data(), plen.data(), ip.data(), flat, iflat, forced))) return rc;
+        std::vector<uint32_t> idx32(idx.begin(), idx.end());
+        H2V_HIP_CHECK(hipMemcpy(d_idx.p + idx_off, idx32.data(), 4 * m, hipMemcpyHostToDevice));
+        h2v_batch* b = nullptr;
+        if ((rc = h2v_batch_create(ctx, m, pl.n_instance_values, &b))) return rc;
+        std::vector<uint8_t> ones(32 * m, 0);
+        for (size_t j = 0; j < m; ++j) ones[32 * j] = 1;      // placeholder draws: the multipliers come from d_mult
+        std::vector<int> st(m, 0); int gok = 0;
+        do {
+            if ((rc = upload_impl(b, m, flat.data(), pl.proof_len, iflat.data(), nc, groups[gi].first.data(), ones.data(), m))) break;
+            b->ext_mult = d_mult.p; b->ext_idx = d_idx.p + idx_off;
+            if ((rc = launch_impl(b, 0))) break;
+            if ((rc = export_records_enqueue(b->stream, b->acc, b->status, b->n, 1, d_records.p + gi * H2V_ACC_RECORD_BYTES))) break;
+            if ((rc = finish_impl(b, st.data(), &gok, nullptr, nullptr))) break;
+        } while (0);
+        h2v_batch_destroy(b);
+        if (rc) return rc;
+        for (size_t j = 0; j < m; ++j) {
+            int v = forced[j] ? forced[j] : st[j];
+            if (per_proof_status) per_proof_status[idx[j]] = v;
+            if (v != 0) all_ok = false;
+        }
+        idx_off += m;
+    }
+    int ok = 0;
+    if ((rc = h2v_fold_check(ctx, d_records.p, groups.size(), &ok, out_left_xy, out_right_xy))) return rc;
+    if (batch_ok) *batch_ok = (ok && all_ok) ? 1 : 0;
+    return 0;
 }
 
 int h2v_verify_each(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,

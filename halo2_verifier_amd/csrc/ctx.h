@@ -7,11 +7,20 @@
 namespace h2v { struct VkDevice; }
 struct h2v_batch;
 
+namespace h2v {
+// staging buffers of h2v_msm_g1, kept between calls (grow-only)
+struct OneShotMsm {
+    uint32_t cap = 0;
+    DevBuf<uint8_t> sb, bb, out; DevBuf<uint32_t> s, flags; DevBuf<G1A> b; DevBuf<G1J> res;
+};
+}  // namespace h2v
+
 struct h2v_ctx {
     int device = 0;
     h2v::ParamsHost params;
     h2v::PairingDevice pairing;
     h2v::MsmWorkspace msm_ws;      // used by h2v_msm_g1 only; batches own their workspaces
+    h2v::OneShotMsm one_shot;
     hipStream_t stream = nullptr;  // used by the synchronous single-shot entry points
     std::mutex mu;                 // serialises the single-shot entry points
     h2v::VkDevice* vk = nullptr;   // per-VK compiled program and constants (vkplan.hip)

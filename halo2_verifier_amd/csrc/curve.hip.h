@@ -7,7 +7,7 @@
 // MSMKZG::eval -> best_multiexp (poly/kzg/msm.rs:81-86, arithmetic.rs:7-108) and through
 // G1Affine::from_bytes (transcript/mod.rs:158-166).
 #pragma once
-#include "bn254.cuh"
+#include "bn254.hip.h"
 
 namespace h2v {
 

@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace h2v {
 
@@ -17,6 +17,20 @@ void set_last_error(const std::string& s);
             return H2V_ERR_DEVICE;                                                              \
         }                                                                                       \
     } while (0)
+
+// Device allocation owned by a scope: error paths that `return` from the middle of an entry point free what they took.
+template <class T> struct DevBuf {
+    T* p = nullptr;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t count) {
+        if (p) { hipFree(p); p = nullptr; }
+        H2V_HIP_CHECK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+        return 0;
+    }
+};
 
 // ------------------------------------------------------------------ MSM (msm.hip)
 // Pippenger over pooled (scalar, base) terms.  Scalars: canonical little-endian 32-bit words, 8 per
@@ -66,6 +80,9 @@ struct MsmWorkspace {
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
     size_t cap_buckets = 0, cap_list = 0;
+    // optional HIP events around msm_accumulate (the dominant kernel: bench.py's roofline.kernels), recorded when `profile` is set
+    bool profile = false, profile_recorded = false;
+    hipEvent_t ev_acc[2] = {nullptr, nullptr};
     // max_terms_per_problem sizes the bucket arrays (the window plan follows the largest problem of a launch)
     int alloc(uint32_t max_total_terms, uint32_t max_problems, uint32_t max_terms_per_problem = 0);
     void release();
@@ -81,7 +98,10 @@ int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, 
 int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
 // Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n);
-// acc[k] = sum_i parts[i * width + k] for k < width (width = 2 x groups: left/right of every group)
-int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc, uint32_t width = 2);
+// Sharded batches exchange H2V_ACC_RECORD_BYTES records per group: [left G1J][right G1J][u32 failed proofs][u32 0].
+// export: d_out[g] <- (acc[2g], acc[2g+1], number of non-zero statuses among the group's n / groups proofs)
+int export_records_enqueue(hipStream_t s, const G1J* d_acc, const int* d_status, uint32_t n, uint32_t groups, void* d_out);
+// fold: acc[2g + c] = sum over parts i of record [i][g]'s channel c; d_fold_failed[g] = sum of the records' failure counts
+int fold_records_enqueue(hipStream_t s, const void* d_parts, uint32_t n_parts, uint32_t groups, G1J* d_acc, uint32_t* d_fold_failed);
 
 }  // namespace h2v

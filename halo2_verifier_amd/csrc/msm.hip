@@ -101,6 +101,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK + 1) * 2 * sizeof(G1JSlot)));
+    for (int i = 0; i < 2; ++i) if (!ev_acc[i]) H2V_HIP_CHECK(hipEventCreate(&ev_acc[i]));
     return 0;
 }
 void MsmWorkspace::release() {
@@ -114,7 +115,8 @@ void MsmWorkspace::release() {
     if (block_sums) hipFree(block_sums);
     if (partial) hipFree(partial);
     counts = offsets = cursor = list = block_sums = nullptr; bucket_pts = window_sums = partial = nullptr; problems = nullptr;
-    cap_terms = 0; cap_problems = 0;
+    for (int i = 0; i < 2; ++i) if (ev_acc[i]) { hipEventDestroy(ev_acc[i]); ev_acc[i] = nullptr; }
+    cap_terms = 0; cap_problems = 0; profile_recorded = false;
 }
 
 // ---- GLV decomposition for BN254 G1 (constants derived in DESIGN.md section 4; lattice basis (a1, b1), (a2, b2) with
@@ -592,7 +594,9 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers its upper bound
     const size_t max_entries = total * 2 * p.windows;
     const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK - 1) / MSM_CHUNK);
+    if (ws.profile) hipEventRecord(ws.ev_acc[0], s);
     hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
+    if (ws.profile) { hipEventRecord(ws.ev_acc[1], s); ws.profile_recorded = true; }
     hipLaunchKernelGGL(msm_fixup_classify, dim3((nb + 255) / 256), dim3(256), 0, s, ws.counts, ws.offsets, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);

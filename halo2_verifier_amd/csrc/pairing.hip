@@ -16,7 +16,7 @@
 // SingleStrategy (one check per proof) launches one such wave per proof.
 #include "../../include/h2v.h"
 #include "internal.h"
-#include "pairing.cuh"
+#include "pairing.hip.h"
 #include "pairing_api.h"
 
 namespace h2v {

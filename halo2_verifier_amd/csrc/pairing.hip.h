@@ -15,7 +15,7 @@
 // Only the boolean is observable through the reference API, so the line-function
 // normalisation and the exponent multiple used in the hard part are free choices.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace h2v {
 

@@ -1,6 +1,6 @@
 #pragma once
 #include "internal.h"
-#include "pairing.cuh"
+#include "pairing.hip.h"
 
 namespace h2v {
 

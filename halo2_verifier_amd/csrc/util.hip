@@ -40,12 +40,46 @@ __global__ void k_point_to_bytes(const G1J* __restrict__ in, uint8_t* __restrict
     for (int j = 0; j < 64; ++j) out[64 * (size_t)i + j] = tmp[j];
 }
 
-__global__ void k_fold_pairs(const G1J* __restrict__ parts, uint32_t n_parts, G1J* __restrict__ acc, uint32_t width) {
+// The record a rank contributes to a sharded batch (include/h2v.h H2V_ACC_RECORD_BYTES): the two accumulator points of one
+// group plus the number of the shard's proofs that failed before the MSM.  A failed proof is zeroed out of its shard's
+// accumulators, so without the flag every OTHER rank's folded pairing would still pass.
+struct AccRecord { G1J left, right; uint32_t failed, reserved; };
+static_assert(sizeof(AccRecord) == H2V_ACC_RECORD_BYTES, "accumulator record layout");
+__global__ void __launch_bounds__(256) k_export_records(const G1J* __restrict__ acc, const int* __restrict__ status, uint32_t gs, AccRecord* __restrict__ out) {
+    __shared__ uint32_t failed;
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    if (t == 0) failed = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t p = t; p < gs; p += 256) mine += status[(size_t)g * gs + p] != 0 ? 1u : 0u;
+    if (mine) atomicAdd(&failed, mine);
+    __syncthreads();
+    if (t == 0) { out[g].left = acc[2 * g]; out[g].right = acc[2 * g + 1]; out[g].failed = failed; out[g].reserved = 0; }
+}
+// acc[2g], acc[2g+1] = sum over parts of the group's left / right points; fold_failed[g] = total failed proofs over all parts
+__global__ void k_fold_records(const AccRecord* __restrict__ parts, uint32_t n_parts, uint32_t groups, G1J* __restrict__ acc, uint32_t* __restrict__ fold_failed) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;  // even: a left channel, odd: a right channel
-    if (k >= width) return;
+    if (k >= 2 * groups) return;
+    const uint32_t g = k >> 1;
     G1J sum = G1J::identity();
-    for (uint32_t i = 0; i < n_parts; ++i) sum = g1_add(sum, parts[(size_t)i * width + k]);
+    uint32_t failed = 0;
+    for (uint32_t i = 0; i < n_parts; ++i) {
+        const AccRecord& r = parts[(size_t)i * groups + g];
+        sum = g1_add(sum, (k & 1) ? r.right : r.left);
+        failed += r.failed;
+    }
     acc[k] = sum;
+    if (!(k & 1)) fold_failed[g] = failed;
+}
+int export_records_enqueue(hipStream_t s, const G1J* d_acc, const int* d_status, uint32_t n, uint32_t groups, void* d_out) {
+    hipLaunchKernelGGL(k_export_records, dim3(groups), dim3(256), 0, s, d_acc, d_status, n / groups, (AccRecord*)d_out);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int fold_records_enqueue(hipStream_t s, const void* d_parts, uint32_t n_parts, uint32_t groups, G1J* d_acc, uint32_t* d_fold_failed) {
+    hipLaunchKernelGGL(k_fold_records, dim3((2 * groups + 63) / 64), dim3(64), 0, s, (const AccRecord*)d_parts, n_parts, groups, d_acc, d_fold_failed);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 __global__ void k_affine_to_jacobian(const G1A* __restrict__ in, G1J* __restrict__ out, uint32_t n) {
@@ -74,11 +108,6 @@ int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* 
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n) {
     if (!n) return 0;
     hipLaunchKernelGGL(k_point_to_bytes, dim3((n + 63) / 64), dim3(64), 0, s, d_in, d_out_xy64, d_is_identity, n);
-    H2V_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-int fold_pairs_enqueue(hipStream_t s, const G1J* d_parts, uint32_t n_parts, G1J* d_acc, uint32_t width) {
-    hipLaunchKernelGGL(k_fold_pairs, dim3((width + 63) / 64), dim3(64), 0, s, d_parts, n_parts, d_acc, width);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -18,10 +18,6 @@
 
 namespace h2v {
 
-__device__ __forceinline__ void status_set(int* status, uint32_t p, int code) {
-    atomicMin(&status[p], code);  // Transcript (-5) outranks Opening (-4): the reference stops at the first failing read
-}
-
 __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
                                                    uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, uint8_t* __restrict__ ycanon,
                                                    int* __restrict__ status) {
@@ -34,7 +30,7 @@ __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict_
     G1A a;
     bool ok = g1_decompress(enc, a);
     // the identity decodes but cannot be absorbed ("cannot write points at infinity to the transcript")
-    if (!ok || a.is_identity()) { status_set(status, p, slot < n_main_points ? H2V_ERR_TRANSCRIPT : H2V_ERR_OPENING); a = G1A::identity(); }
+    if (!ok || a.is_identity()) { status_set(status, p, slot < n_main_points ? H2V_DEV_ST_TRANSCRIPT : H2V_DEV_ST_OPENING); a = G1A::identity(); }
     pts[(size_t)p * np + slot] = a;
     uint8_t yb[32];
     a.y.to_bytes(yb);
@@ -52,7 +48,7 @@ __global__ void __launch_bounds__(256) k_check_scalars(const uint8_t* __restrict
     uint32_t raw[8];
     for (int j = 0; j < 8; ++j) raw[j] = (uint32_t)b[4 * j] | ((uint32_t)b[4 * j + 1] << 8) | ((uint32_t)b[4 * j + 2] << 16) | ((uint32_t)b[4 * j + 3] << 24);
     // a non-canonical public input cannot be represented as an Fr on the reference side at all: bad argument for that proof
-    if (Fr::geq_p(raw)) status_set(status, p, i < ns ? H2V_ERR_TRANSCRIPT : H2V_ERR_INVALID_INSTANCES);
+    if (Fr::geq_p(raw)) status_set(status, p, i < ns ? H2V_DEV_ST_TRANSCRIPT : H2V_DEV_ST_INVALID_INSTANCES);
 }
 
 __global__ void __launch_bounds__(256) k_stream_build(const TranscriptSrc* __restrict__ stream, uint32_t stream_len, const uint8_t* __restrict__ proofs,
@@ -311,7 +307,7 @@ __global__ void __launch_bounds__(INSTEVAL_THREADS) k_instance_eval(InstEvalArgs
         if (t < d) red[t] = red[t] + red[t + d];
         __syncthreads();
     }
-    if (zero_den) status_set(a.status, p, H2V_ERR_REFERENCE_PANIC);
+    if (zero_den) status_set(a.status, p, H2V_DEV_ST_PANIC);
     if (t == 0) {
         Fr xn = x;
         for (uint32_t i = 0; i < a.k; ++i) xn = xn.sqr();
@@ -348,7 +344,7 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
             case OP_NEG: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p).neg()); break;
             case OP_INV: {
                 Fr v = slot_load(a.slots, in.a, n, p);
-                if (v.is_zero()) atomicCAS(&a.status[p], 0, H2V_ERR_REFERENCE_PANIC);
+                if (v.is_zero()) status_set(a.status, p, H2V_DEV_ST_PANIC);
                 // all lanes invert at once: the fixed-exponent chain is uniform across the wave, unlike the data-dependent
                 // steps of the binary-GCD inverse, which a lone lane (affine conversion, pairing) prefers
                 slot_store(a.slots, in.d, n, p, v.inv_fermat());
@@ -458,6 +454,16 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
 }
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult) {
     hipLaunchKernelGGL(k_multipliers, dim3(groups), dim3(1024), 0, s, d_tail, n_tail / groups, n / groups, d_mult);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+__global__ void __launch_bounds__(256) k_gather_multipliers(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, Fr* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+int gather_multipliers_enqueue(hipStream_t s, const Fr* d_src, const uint32_t* d_idx, uint32_t n, Fr* d_out) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_gather_multipliers, dim3((n + 255) / 256), dim3(256), 0, s, d_src, d_idx, n, d_out);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,5 +1,5 @@
 // Host side: VerifyingKey ingestion and compilation of the per-VK verification plan
-// (see vkplan.h).  Pure host code; compiled by hipcc because it shares bn254.cuh with the kernels.
+// (see vkplan.h).  Pure host code; compiled by hipcc because it shares bn254.hip.h with the kernels.
 #include "../../include/h2v.h"
 #include "ctx.h"
 #include "vkplan.h"

@@ -2,8 +2,7 @@
 
 The reference has no communication layer.  Proofs are independent until the final
 pairing, so the batch is cut into contiguous shards; every rank runs the whole per-proof pipeline
-and its two pooled MSMs, and the only exchange is an all-gather of 2 G1 points (2 x 108 bytes) per
-rank — RCCL has no user-defined reduction, and a group addition is not a numeric sum — followed
+and its two pooled MSMs, and the only exchange is an all-gather of one 224-byte record per rank and group (2 G1 points of 108 bytes + the shard's failed-proof count) — RCCL has no user-defined reduction, and a group addition is not a numeric sum — followed
 by a 2(N-1)-addition fold and ONE pairing (DualMSM::add_msm + check, poly/kzg/msm.rs:178-203).
 
 Multipliers: proof i of the whole batch is scaled by the product of the Fr::random draws of all
@@ -19,7 +18,10 @@ def shard_bounds(total: int, world_size: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-ACC_BYTES = 216  # 2 x Jacobian G1 (3 coordinates x 9 limbs x 4 B, the library's Montgomery limb layout)
+# include/h2v.h H2V_ACC_RECORD_BYTES: 2 x Jacobian G1 (3 coordinates x 9 limbs x 4 B, the library's Montgomery limb layout)
+# + u32 count of the shard's failed proofs + u32 zero.  The count travels with the points so that every rank clears the
+# verdict when ANY shard rejected a proof (a failed proof contributes nothing to its shard's accumulators).
+ACC_BYTES = 224
 
 
 def gather_accumulators(local_acc, world_size, group=None):

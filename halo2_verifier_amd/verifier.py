@@ -11,7 +11,10 @@ import enum
 import os
 
 from . import _lib
+from . import distributed
 from ._lib import H2VError, check
+
+_FR_MODULUS = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 
 
 class SerdeFormat(enum.IntEnum):  # helpers.rs:7-19
@@ -79,6 +82,19 @@ class VerifyingKey:
     from_bytes = read
 
 
+def _scalar32(v) -> bytes:
+    """One field element at the boundary: 32 little-endian bytes.  The C side reads exactly 32 bytes per scalar, so a
+    shorter bytes object would make it read past the Python buffer: reject it here."""
+    if isinstance(v, (bytes, bytearray, memoryview)):
+        if len(v) != 32:
+            raise ValueError(f"a scalar given as bytes must be exactly 32 bytes, got {len(v)}")
+        return bytes(v)
+    v = int(v)
+    if v < 0 or v >> 256:
+        raise ValueError("a scalar given as an integer must be in [0, 2^256)")
+    return v.to_bytes(32, "little")
+
+
 def _flatten_instances(instances):
     """instances: list (columns) of lists of 32-byte scalars (or ints) -> (flat bytes, col_lens)"""
     flat = bytearray()
@@ -86,8 +102,34 @@ def _flatten_instances(instances):
     for col in instances:
         lens.append(len(col))
         for v in col:
-            flat += v if isinstance(v, (bytes, bytearray)) else int(v).to_bytes(32, "little")
+            flat += _scalar32(v)
     return bytes(flat), lens
+
+
+def _marshal_batch(ctx, proofs, instances):
+    """Pointer arrays for h2v_verify_batch / h2v_verify_each.  Everything the C side will index is checked here: one
+    instance list per proof, proofs are bytes, every scalar is 32 bytes.  Returns (n, proof ptrs, proof lens, instance
+    ptrs, per-proof column lengths [n][ncols], keep-alive list)."""
+    n = len(proofs)
+    if len(instances) != n:
+        raise ValueError(f"{n} proofs but {len(instances)} instance lists: verify_proof takes one per proof (lib.rs:33-49)")
+    for p in proofs:
+        if not isinstance(p, (bytes, bytearray)):
+            raise TypeError("proofs must be bytes")
+    PA = ctypes.c_char_p * max(n, 1)
+    pa = PA(*[bytes(p) for p in proofs]) if n else PA()
+    pl = (ctypes.c_size_t * max(n, 1))(*[len(p) for p in proofs])
+    flats, shapes = [], []
+    for inst in instances:
+        f, l = _flatten_instances(inst)
+        flats.append(f)
+        shapes.append(l)
+    ncols = len(shapes[0]) if shapes else ctx.proof_shape()["n_instance_columns"]
+    for l in shapes:
+        if len(l) != ncols:
+            raise ValueError("all proofs of a batch must have the same number of instance columns")
+    ia = PA(*flats) if n else PA()
+    return n, pa, pl, ia, shapes, ncols, flats
 
 
 class Context:
@@ -117,7 +159,10 @@ class Context:
     # -- MSMKZG::eval (poly/kzg/msm.rs:81-86)
     def msm_g1(self, scalars, bases):
         """scalars: iterable of ints / 32-byte LE; bases: iterable of 64-byte x|y. -> 64-byte x|y (zeros = identity)"""
-        sb = b"".join(s if isinstance(s, (bytes, bytearray)) else int(s).to_bytes(32, "little") for s in scalars)
+        sb = b"".join(_scalar32(s) for s in scalars)
+        bases = list(bases)
+        if any(len(b) != 64 for b in bases):
+            raise ValueError("every base must be 64 bytes (x | y)")
         bb = b"".join(bases)
         n = len(sb) // 32
         if len(bb) != 64 * n:
@@ -130,6 +175,8 @@ class Context:
     # -- DualMSM::check (poly/kzg/msm.rs:185-203)
     def pairing_check(self, left_xy: bytes, right_xy: bytes) -> bool:
         ok = ctypes.c_int(0)
+        if len(left_xy) != 64 or len(right_xy) != 64:
+            raise ValueError("points are 64 bytes (x | y)")
         check(self._lib.h2v_pairing_check(self._h, left_xy, right_xy, ctypes.byref(ok)))
         return bool(ok.value)
 
@@ -141,50 +188,46 @@ class Context:
 
     # -- N x verify_proof + AccumulatorStrategy::finalize
     def verify_batch(self, proofs, instances, rand=None):
-        """proofs: list of bytes; instances: per proof, list of columns of scalars; rand: list of n ints/bytes or None.
+        """proofs: list of bytes; instances: per proof, list of columns of scalars (column lengths may differ from proof to
+        proof, as N independent verify_proof calls allow); rand: list of n ints/bytes or None.
         Returns (batch_ok, statuses, left_xy, right_xy)."""
-        n = len(proofs)
-        PA = ctypes.c_char_p * max(n, 1)
-        pa = PA(*proofs) if n else PA()
-        pl = (ctypes.c_size_t * max(n, 1))(*[len(p) for p in proofs])
-        flats, lens = [], None
-        for inst in instances:
-            f, l = _flatten_instances(inst)
-            if lens is not None and l != lens:
-                raise ValueError("all proofs of a batch must share one instance shape")
-            lens = l
-            flats.append(f)
-        if lens is None:  # empty batch: the column count comes from the VK
-            lens = [0] * self.proof_shape()["n_instance_columns"]
-        ia = PA(*flats) if n else PA()
-        cl = (ctypes.c_size_t * max(len(lens), 1))(*lens)
+        n, pa, pl, ia, shapes, ncols, _keep = _marshal_batch(self, proofs, instances)
         rb = None
         if rand is not None:
-            rb = b"".join(r if isinstance(r, (bytes, bytearray)) else int(r).to_bytes(32, "little") for r in rand)
+            if len(rand) != n:
+                raise ValueError(f"rand must hold one scalar per proof ({n}), got {len(rand)}")   # the C side reads n * 32 bytes
+            rb = b"".join(_scalar32(r) for r in rand)
         st = (ctypes.c_int * max(n, 1))()
         ok = ctypes.c_int(0)
         left = ctypes.create_string_buffer(64)
         right = ctypes.create_string_buffer(64)
-        check(self._lib.h2v_verify_batch(self._h, n, pa, pl, ia, len(lens), cl, rb, st, ctypes.byref(ok), left, right))
+        if all(l == shapes[0] for l in shapes):
+            lens = shapes[0] if shapes else [0] * ncols
+            cl = (ctypes.c_size_t * max(ncols, 1))(*lens)
+            check(self._lib.h2v_verify_batch(self._h, n, pa, pl, ia, ncols, cl, rb, st, ctypes.byref(ok), left, right))
+        else:
+            cl = (ctypes.c_size_t * max(n * ncols, 1))(*[v for l in shapes for v in l])
+            check(self._lib.h2v_verify_batch_shapes(self._h, n, pa, pl, ia, ncols, cl, rb, st, ctypes.byref(ok), left, right))
         return bool(ok.value), list(st)[:n], left.raw, right.raw
 
     def verify_each(self, proofs, instances):
-        n = len(proofs)
-        PA = ctypes.c_char_p * max(n, 1)
-        pa = PA(*proofs) if n else PA()
-        pl = (ctypes.c_size_t * max(n, 1))(*[len(p) for p in proofs])
-        flats, lens = [], None
-        for inst in instances:
-            f, l = _flatten_instances(inst)
-            lens = l
-            flats.append(f)
-        if lens is None:
-            lens = [0] * self.proof_shape()["n_instance_columns"]
-        ia = PA(*flats) if n else PA()
-        cl = (ctypes.c_size_t * max(len(lens), 1))(*lens)
+        n, pa, pl, ia, shapes, ncols, _keep = _marshal_batch(self, proofs, instances)
         st = (ctypes.c_int * max(n, 1))()
-        check(self._lib.h2v_verify_each(self._h, n, pa, pl, ia, len(lens), cl, st))
-        return list(st)[:n]
+        if all(l == shapes[0] for l in shapes):
+            lens = shapes[0] if shapes else [0] * ncols
+            cl = (ctypes.c_size_t * max(ncols, 1))(*lens)
+            check(self._lib.h2v_verify_each(self._h, n, pa, pl, ia, ncols, cl, st))
+            return list(st)[:n]
+        # SingleStrategy proofs are independent: run every instance shape as its own call and put the statuses back in order
+        out = [0] * n
+        by_shape = {}
+        for i, l in enumerate(shapes):
+            by_shape.setdefault(tuple(l), []).append(i)
+        for l, idx in by_shape.items():
+            sub = self.verify_each([proofs[i] for i in idx], [instances[i] for i in idx])
+            for i, v in zip(idx, sub):
+                out[i] = v
+        return out
 
     def guard_msm(self, proof, instances, cap=4096):
         f, lens = _flatten_instances(instances)
@@ -215,15 +258,63 @@ class AccumulatorStrategy(_Strategy):
         self.rand, self.device = rand, device
 
     def finalize(self) -> bool:
+        """One pairing for everything that was accumulated.  verify_proof takes a VK per call and one strategy may accumulate
+        proofs of DIFFERENT VKs over the same params (kzg/strategy.rs:125-140 only ever sees MSMs): proofs are grouped by VK,
+        every VK gets its own context and accumulator pair (no pairing), the draws are indexed by call order over ALL queued
+        proofs (proof i is scaled by the product of the draws of all later proofs, whatever their VK), and the accumulator
+        records are folded by h2v_fold_check into the single pairing."""
         if not self._items:
             return True  # empty DualMSM: both channels are the identity, e(0,..)e(0,..) == 1
-        vk = self._items[0][0]
-        ctx = Context(self.params, vk, self.device)
+        n = len(self._items)
+        rand = self.rand
+        if rand is not None and len(rand) != n:
+            raise ValueError(f"rand must hold one scalar per accumulated proof ({n}), got {len(rand)}")
+        groups = {}
+        for i, (vk, _, _) in enumerate(self._items):
+            groups.setdefault((vk.data, int(vk.format)), []).append(i)
+        if len(groups) == 1:
+            ctx = Context(self.params, self._items[0][0], self.device)
+            try:
+                ok, _, _, _ = ctx.verify_batch([p for _, _, p in self._items], [i for _, i, _ in self._items], rand)
+                return ok
+            finally:
+                ctx.close()
+        return self._finalize_mixed(groups, rand)
+
+    def _finalize_mixed(self, groups, rand):
+        import torch  # device memory for the gathered records (plumbing only)
+        lib = _lib.load_library()
+        n = len(self._items)
+        if rand is None:
+            rand = [int.from_bytes(os.urandom(64), "little") % _FR_MODULUS for _ in range(n)]
+        rb = [_scalar32(r) for r in rand]
+        # A VK's proofs are not contiguous in call order, so the library's "tail" convention (multiplier = product of the later
+        # draws of the SAME upload) is fed per proof: proof i is uploaded as a one-proof shard whose tail is the draws of
+        # proofs (i, n) of the whole accumulated sequence.  Mixed-VK accumulation is a rare path; clarity over speed.
+        records = torch.zeros(n * distributed.ACC_BYTES, dtype=torch.uint8, device=f"cuda:{self.device}")
+        ctxs, ok_all = {}, True
         try:
-            ok, statuses, _, _ = ctx.verify_batch([p for _, _, p in self._items], [i for _, i, _ in self._items], self.rand)
-            return ok
+            for key, idx in groups.items():
+                ctx = ctxs[key] = Context(self.params, self._items[idx[0]][0], self.device)
+                for i in idx:
+                    _, inst, proof = self._items[i]
+                    flat, lens = _flatten_instances(inst)
+                    b = Batch(ctx, 1, max(sum(lens), 1))
+                    try:
+                        b.upload(proof, len(proof), flat, lens, b"".join(rb[i:]))
+                        b.launch(with_pairing=False)
+                        b.export_accumulators(records.data_ptr() + i * distributed.ACC_BYTES)
+                        _, st, _, _ = b.finish()
+                        ok_all = ok_all and st == [0]
+                    finally:
+                        b.close()
+            ok = ctypes.c_int(0)
+            any_ctx = next(iter(ctxs.values()))
+            check(lib.h2v_fold_check(any_ctx._h, ctypes.c_void_p(records.data_ptr()), n, ctypes.byref(ok), None, None))
+            return bool(ok.value) and ok_all
         finally:
-            ctx.close()
+            for c in ctxs.values():
+                c.close()
 
 
 class SingleStrategy(_Strategy):
@@ -262,7 +353,7 @@ class Batch:
     """Staged, device-resident batch (h2v_batch): upload once, launch asynchronously on its stream, finish later.
     Several batches may be in flight on one Context (one HIP stream each)."""
 
-    STAGES = ("decompress", "transcript", "fr_program", "fold", "msm", "pairing")
+    STAGES = ("decompress", "transcript", "fr_program", "fold", "msm", "pairing", "msm_accumulate")   # the last one lies inside "msm"
 
     def __init__(self, ctx: Context, max_proofs: int, max_instance_values: int = 0, stream=None, groups: int = 1):
         self.ctx, self._lib = ctx, ctx._lib
@@ -304,6 +395,13 @@ class Batch:
         """proofs_flat: n * proof_len bytes; instances_flat: n * sum(col_lens) * 32 bytes;
         rand_tail: bytes of the Fr::random draws of proofs [first, total) of the whole batch (>= n scalars) or None."""
         n = len(proofs_flat) // proof_len if proof_len else 0
+        # the C side reads n * proof_len, n * sum(col_lens) * 32 and n_tail * 32 bytes: the buffers must hold exactly that
+        if proof_len and len(proofs_flat) != n * proof_len:
+            raise ValueError("proofs_flat is not a whole number of proofs")
+        if len(instances_flat) != n * sum(col_lens) * 32:
+            raise ValueError(f"instances_flat must be n * sum(col_lens) * 32 = {n * sum(col_lens) * 32} bytes, got {len(instances_flat)}")
+        if rand_tail is not None and len(rand_tail) % 32:
+            raise ValueError("rand_tail is not a whole number of 32-byte scalars")
         cl = (ctypes.c_size_t * max(len(col_lens), 1))(*col_lens)
         nt = len(rand_tail) // 32 if rand_tail is not None else 0
         check(self._lib.h2v_batch_upload(self._h, n, proofs_flat, proof_len, instances_flat, len(col_lens), cl, rand_tail, nt))
@@ -340,6 +438,6 @@ class Batch:
         check(self._lib.h2v_batch_set_profiling(self._h, 1 if on else 0))
 
     def timings_ms(self):
-        arr = (ctypes.c_float * 6)()
-        k = self._lib.h2v_batch_timings(self._h, arr, 6)
+        arr = (ctypes.c_float * len(self.STAGES))()
+        k = self._lib.h2v_batch_timings(self._h, arr, len(self.STAGES))
         return dict(zip(self.STAGES, list(arr)[:k]))

@@ -117,6 +117,18 @@ int h2v_verify_batch(h2v_ctx* ctx, size_t n,
                      int* per_proof_status, int* batch_ok,
                      uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
 
+/* As h2v_verify_batch, but every proof brings its own instance column lengths — what N independent calls of the reference's
+ * verify_proof allow (`instances: &[&[&[Fr]]]` is an argument of each call, lib.rs:33-49).  col_lens_per_proof is
+ * [n][n_instance_columns]; instances32[i] is the concatenation of proof i's columns.  Proofs are grouped by shape inside the
+ * library (one compiled plan per shape); the multipliers follow call order over the whole batch and ONE pairing closes it, so
+ * the result equals n calls of verify_proof on one AccumulatorStrategy followed by finalize(). */
+int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n,
+                            const uint8_t* const* proofs, const size_t* proof_lens,
+                            const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens_per_proof,
+                            const uint8_t* rand32,
+                            int* per_proof_status, int* batch_ok,
+                            uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
+
 /* N x verify_proof under SingleStrategy (one pairing per proof; poly/kzg/strategy.rs:164-176).
  * per_proof_status[i] = 0, or H2V_ERR_CONSTRAINT_SYSTEM_FAILURE when that proof's pairing fails,
  * or the transcript/opening error. */
@@ -137,8 +149,8 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len,
 
 /* ---- staged interface: inputs resident in HBM, asynchronous execution on the batch's stream.
  * h2v_verify_batch == upload + launch + finish.  A sharded (multi-GPU) run uses
- * h2v_batch_launch_accumulate on every rank, exchanges the 2 accumulator points, and calls
- * h2v_fold_check once. */
+ * h2v_batch_launch(b, 0) on every rank, exchanges the accumulator records (h2v_batch_export_accumulators),
+ * and closes with h2v_batch_fold_check_enqueue (or h2v_fold_check). */
 int h2v_batch_create(h2v_ctx* ctx, size_t max_proofs, size_t max_instance_values_per_proof, h2v_batch** out);
 void h2v_batch_destroy(h2v_batch* b);
 /* Host -> device copy of one shard.  proofs_flat = n * proof_len bytes, instances_flat = n * (sum col_lens) * 32 bytes.
@@ -161,27 +173,36 @@ int h2v_batch_set_groups(h2v_batch* b, size_t groups);
 /* As h2v_batch_finish for a grouped batch: group_ok[n_groups], out_left_xy / out_right_xy = n_groups x 64 bytes. */
 int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left_xy, uint8_t* out_right_xy, size_t n_groups);
 /* Device address of this batch's accumulator points after launch: per group [left, right], 2 x 108 bytes each, Jacobian
- * (X, Y, Z) in the library's Montgomery limb layout — opaque bytes to be moved by a collective. */
+ * (X, Y, Z) in the library's Montgomery limb layout (debug / inspection; the record a sharded run exchanges is written by
+ * h2v_batch_export_accumulators). */
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes);
+/* What a shard contributes to a sharded batch, per group: [left point 108 B][right point 108 B][u32 number of this shard's
+ * proofs with a non-zero status][u32 0] — opaque bytes to be moved by a collective (all-gather).  The failure count matters:
+ * a failed proof is zeroed out of its shard's accumulators, so the folded pairing alone would accept a batch in which another
+ * shard rejected a proof; h2v_batch_fold_check_enqueue / h2v_fold_check clear `ok` when any folded record reports failures,
+ * so every rank reaches the same verdict without a second collective. */
+#define H2V_ACC_RECORD_BYTES 224
 /* The HIP stream (hipStream_t) the batch runs on, for event timing and stream-ordered interop. */
 void* h2v_batch_stream(h2v_batch* b);
 /* Run the batch on a caller-owned stream (e.g. a torch.cuda.Stream's cuda_stream) instead of its own,
  * so that collectives issued by the caller on that stream are ordered with the batch's kernels without
  * host synchronisation.  The caller keeps the stream alive while the batch uses it. */
 int h2v_batch_set_stream(h2v_batch* b, void* hip_stream);
-/* Stream-ordered copy of the accumulator points (groups x 2 x 108 bytes) into caller device memory. */
+/* Stream-ordered write of the batch's accumulator records (groups x H2V_ACC_RECORD_BYTES) into caller device memory. */
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst);
 /* Stream-ordered version of h2v_fold_check on the batch's stream: fold n_parts gathered accumulator
  * sets (each laid out as h2v_batch_export_accumulators writes it: [group][left, right]) group by group and enqueue one
- * pairing per group; the result is fetched by h2v_batch_finish / h2v_batch_finish_groups (ok, left, right). */
+ * pairing per group; the result is fetched by h2v_batch_finish / h2v_batch_finish_groups (ok, left, right): a group is ok
+ * when its pairing passes, its local proofs are all ok AND no folded record reports a failed proof. */
 int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts);
-/* Fold n_parts accumulator pairs (as produced by h2v_batch_accumulators, contiguous in device
- * memory) with G1 additions and run the single pairing check.
+/* Fold n_parts accumulator records (as written by h2v_batch_export_accumulators for an ungrouped batch, contiguous in
+ * device memory) with G1 additions and run the single pairing check; ok = pairing passed and no record reports a failed proof.
  *   replaces: DualMSM::add_msm + check across shards (poly/kzg/msm.rs:178-203). */
 int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts, int* ok,
                    uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
 /* Per-stage device time of the last finished launch, milliseconds, measured with HIP events on
- * the batch's stream: [decompress, transcript, fr_program, fold, msm, pairing]; returns count. */
+ * the batch's stream: [decompress, transcript, fr_program, fold, msm, pairing, msm_accumulate (the dominant kernel
+ * inside the msm stage)]; returns the number of entries written (<= cap). */
 int h2v_batch_timings(h2v_batch* b, float* ms, int cap);
 int h2v_batch_set_profiling(h2v_batch* b, int enabled);
 

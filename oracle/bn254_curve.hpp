@@ -37,7 +37,7 @@ struct G1Affine {
 // Compressed encoding of the halo2curves line the fork tracks (>= 0.4): 32 bytes, x little
 // endian in the low 254 bits; byte 31 bit 7 = identity flag, bit 6 = sign = y.to_repr()[0] & 1.
 // This is the one detail nothing in /root/reference pins (SURVEY.md §8c "Unpinned detail");
-// it is a single pair of constants here and in the product (csrc/bn254.cuh).
+// it is a single pair of constants here and in the product (csrc/bn254.hip.h).
 static const uint8_t G1_FLAG_IDENTITY = 0x80;
 static const uint8_t G1_FLAG_SIGN = 0x40;
 

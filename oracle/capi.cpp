@@ -207,6 +207,22 @@ size_t h2o_prove_vector_mul(void* h, const uint8_t* a32, const uint8_t* b32, uin
     Rng rng(rng_seed);
     return copy_out(create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng, s->multiopen, s->transcript), proof, cap);
 }
+// vector_mul with a SHORTER instance vector: the public inputs are the first inst_len products; the caller makes the remaining
+// products zero (b_i = 0), so the circuit's copy constraints hold against an instance column that is zero beyond inst_len.
+// The prover absorbs exactly inst_len values — what verify_proof is handed per call (`instances`, lib.rs:33-49, 76-82).
+size_t h2o_prove_vector_mul_len(void* h, const uint8_t* a32, const uint8_t* b32, size_t inst_len, uint64_t rng_seed, uint8_t* proof, size_t cap, uint8_t* instances_out) {
+    Setup* s = (Setup*)h;
+    if (inst_len > s->n_mul) return 0;
+    std::vector<Fr> a(s->n_mul), b(s->n_mul), c(inst_len);
+    for (size_t i = 0; i < s->n_mul; ++i) {
+        Fr::from_bytes(a32 + 32 * i, a[i]); Fr::from_bytes(b32 + 32 * i, b[i]);
+        Fr prod = a[i] * b[i];
+        if (i < inst_len) { c[i] = prod; if (instances_out) c[i].to_bytes(instances_out + 32 * i); }
+        else if (!(prod == Fr::zero())) return 0;
+    }
+    Rng rng(rng_seed);
+    return copy_out(create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng, s->multiopen, s->transcript), proof, cap);
+}
 // batch of `count` distinct proofs with pseudo-random a, b derived from seed+i; nthreads workers
 size_t h2o_prove_vector_mul_batch(void* h, size_t count, uint64_t seed, unsigned nthreads, uint8_t* proofs, size_t proof_len, uint8_t* instances_out) {
     Setup* s = (Setup*)h;

@@ -67,6 +67,17 @@ def prove_vector_mul(s, a, b, rng_seed=7):
     return buf.raw[:n], [[inst.raw[32 * i:32 * i + 32] for i in range(s.n_mul)]]
 
 
+def prove_vector_mul_len(s, a, b, inst_len, rng_seed=7):
+    """As prove_vector_mul with only the first inst_len products public (the rest must be zero): instances [[c_0..c_{len-1}]]"""
+    ab = b"".join(le32(x) for x in a)
+    bb = b"".join(le32(x) for x in b)
+    buf = ctypes.create_string_buffer(1 << 16)
+    inst = ctypes.create_string_buffer(32 * max(inst_len, 1))
+    n = s.L.h2o_prove_vector_mul_len(s.h, ab, bb, inst_len, rng_seed, buf, len(buf), inst)
+    assert n > 0
+    return buf.raw[:n], [[inst.raw[32 * i:32 * i + 32] for i in range(inst_len)]]
+
+
 def prove_vector_mul_batch(s, count, seed=1, threads=8, proof_len=None):
     if proof_len is None:
         proof_len = len(prove_vector_mul(s, [1] * s.n_mul, [1] * s.n_mul)[0])
@@ -163,3 +174,38 @@ def oracle_verify_batch(s, proofs, instances, rand):
     rc = s.L.h2o_verify_batch(s.params, len(s.params), RAW, s.vk, len(s.vk), RAW, n, pf, plen, flat, cl, nc, rb, st, ctypes.byref(ok), left, right)
     assert rc == 0, rc
     return bool(ok.value), list(st)[:n], left.raw, right.raw
+
+
+def oracle_pairing_check(s, left_xy, right_xy):
+    """DualMSM::check on two evaluated channels (poly/kzg/msm.rs:185-203) by the oracle"""
+    ok = ctypes.c_int(0)
+    rc = s.L.h2o_pairing_check(s.params, len(s.params), RAW, left_xy, right_xy, ctypes.byref(ok))
+    assert rc == 0, rc
+    return bool(ok.value)
+
+
+def oracle_accumulate(items, rand):
+    """N x verify_proof on ONE AccumulatorStrategy followed by finalize(), restated from the oracle's per-proof Guards:
+    items = [(setup, proof, instances)] in call order (setups may differ in VK and instance shape, same params); proof i's Guard
+    is scaled by the product of the draws of all LATER proofs (kzg/strategy.rs:129, msm.rs:173-176: process() scales the
+    accumulator by a fresh draw before adding the next Guard).  -> (ok, statuses, left_xy, right_xy)"""
+    n = len(items)
+    mult = [1] * n
+    run = 1
+    for i in range(n - 1, -1, -1):
+        mult[i] = run
+        run = run * (int.from_bytes(rand[i], "little") if isinstance(rand[i], (bytes, bytearray)) else int(rand[i])) % R_MOD
+    ls, lb, rs, rb, statuses = [], [], [], [], []
+    for (s, proof, inst), m in zip(items, mult):
+        rc, g = oracle_guard(s, proof, inst)
+        statuses.append(rc)
+        if rc != 0:
+            continue
+        ls += [int.from_bytes(x, "little") * m % R_MOD for x in g["left_scalars"]]; lb += g["left_bases"]
+        rs += [int.from_bytes(x, "little") * m % R_MOD for x in g["right_scalars"]]; rb += g["right_bases"]
+    L = items[0][0].L
+    zero = b"\0" * 64
+    left = oracle_lib.g1_msm(L, ls, lb) if ls else zero
+    right = oracle_lib.g1_msm(L, rs, rb) if rs else zero
+    ok = oracle_pairing_check(items[0][0], left, right) and not any(statuses)
+    return ok, statuses, left, right

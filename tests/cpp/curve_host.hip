@@ -1,4 +1,4 @@
-// Host-side exerciser of the product's G1 group law (halo2_verifier_amd/csrc/curve.cuh), including the in-place fast
+// Host-side exerciser of the product's G1 group law (halo2_verifier_amd/csrc/curve.hip.h), including the in-place fast
 // forms that REPORT the degenerate cases instead of handling them.  Lines on stdin:
 //   add x1 y1 x2 y2 | madd x1 y1 x2 y2 | dbl x1 y1 | fast_madd x1 y1 x2 y2 | fast_add x1 y1 x2 y2 | scaled k x1 y1 x2 y2
 // coordinates as 64 hex digits ("0"*64, "0"*64 = the identity).  `scaled k`: P1 is first mapped to Jacobian coordinates with
@@ -8,7 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "../../halo2_verifier_amd/csrc/curve.cuh"
+#include "../../halo2_verifier_amd/csrc/curve.hip.h"
 using namespace h2v;
 namespace h2v { void set_last_error(const std::string&) {} }
 

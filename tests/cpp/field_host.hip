@@ -1,11 +1,11 @@
-// Host-side exerciser of the product's own field arithmetic (halo2_verifier_amd/csrc/bn254.cuh is __host__ __device__:
+// Host-side exerciser of the product's own field arithmetic (halo2_verifier_amd/csrc/bn254.hip.h is __host__ __device__:
 // the plan compiler and the G2 line precomputation run it on the CPU).  Reads lines "op a b" with a, b 64-hex-digit
 // big-endian residues (op in: mul sqr add sub neg inv dot2 [a b c d] ...) from stdin for the field named by argv[1]
 // (fq | fr) and prints the canonical result as 64 hex digits.  tests/test_field_host.py drives it against Python big ints.
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include "../../halo2_verifier_amd/csrc/bn254.cuh"
+#include "../../halo2_verifier_amd/csrc/bn254.hip.h"
 using namespace h2v;
 
 template <class F> struct FP29;

@@ -1,4 +1,4 @@
-// Host-side exerciser of the extension tower of csrc/pairing.cuh (Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3 - xi),
+// Host-side exerciser of the extension tower of csrc/pairing.hip.h (Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3 - xi),
 // Fq12 = Fq6[w]/(w^2 - v), xi = 9 + u), which the library runs on the CPU for the G2 line precomputation and on one lane
 // for the Fq6 inversion of the final exponentiation.  stdin: "mul|inv|frob <12 x 64-hex> [<12 x 64-hex>]" with the twelve
 // Fq coefficients in the order c0.c0.c0 c0.c0.c1 c0.c1.c0 ... (Fq6 c0 then c1; inside Fq6: c0, c1, c2; inside Fq2: c0, c1).
@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include "../../halo2_verifier_amd/csrc/pairing.cuh"
+#include "../../halo2_verifier_amd/csrc/pairing.hip.h"
 using namespace h2v;
 namespace h2v { void set_last_error(const std::string&) {} }
 

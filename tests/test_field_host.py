@@ -1,4 +1,4 @@
-"""The product's own field arithmetic (halo2_verifier_amd/csrc/bn254.cuh: 9 x 29-bit limbs, R = 2^261, lazily reduced) run
+"""The product's own field arithmetic (halo2_verifier_amd/csrc/bn254.hip.h: 9 x 29-bit limbs, R = 2^261, lazily reduced) run
 on the HOST — it is __host__ __device__, and the plan compiler executes it on the CPU — against Python big integers:
 random operands, the edge values 0, 1, p-1, and chains whose intermediates sit in [p, 2p).  No GPU needed."""
 import os

@@ -100,7 +100,8 @@ def test_grouped_and_sharded(pool):
     rand = [[rnd.randrange(1, R_MOD) for _ in range(per_group)] for _ in range(G)]
     proofs = [P[g * per_group:(g + 1) * per_group] for g in range(G)]
     insts = [I[g * per_group:(g + 1) * per_group] for g in range(G)]
-    acc_bytes = 216 * G
+    from halo2_verifier_amd import distributed as h2d
+    acc_bytes = h2d.ACC_BYTES * G
     acc = torch.zeros(R * acc_bytes, dtype=torch.uint8, device="cuda:0")
     batches = []
     for r in range(R):

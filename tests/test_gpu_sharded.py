@@ -49,7 +49,9 @@ def _sharded(ctx, P, I, rand, R):
     ok, _, left, right = batches[0].finish()
     for b in batches:
         b.close()
-    return ok and not any(statuses), statuses, left, right
+    # `ok` is the FOLDING batch's verdict alone: the exchanged records carry every shard's failed-proof count
+    # (H2V_ACC_RECORD_BYTES), so no status AND across shards is needed on the host
+    return ok, statuses, left, right
 
 
 def _ctx(s):
@@ -67,6 +69,28 @@ def test_sharded_equals_unsharded(big, R):
     ref = ctx.verify_batch(P[:n], I[:n], rand)
     got = _sharded(ctx, P[:n], I[:n], rand, R)
     assert got == ref and got[0] is True
+    ctx.close()
+
+
+def test_failed_proof_on_a_non_folding_shard_rejects_the_batch(big):
+    """A proof that fails BEFORE the MSM (undecodable point) is zeroed out of its shard's accumulators, so the folded pairing
+    alone would pass.  The record a shard exports carries its failed-proof count; the rank that folds (shard 0 here, which
+    holds only good proofs) must clear the verdict.  ADVICE r1, batch.hip finish_impl."""
+    s, P, I = big
+    ctx = _ctx(s)
+    n = 24
+    rnd = random.Random(99)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    bad = list(P[:n])
+    b = bytearray(bad[19]); b[0:32] = b"\xff" * 32; bad[19] = bytes(b)      # first advice commitment: x >= p, not decodable
+    ref = ctx.verify_batch(bad, I[:n], rand)
+    assert ref[0] is False and ref[1][19] == -5 and sum(1 for v in ref[1] if v) == 1
+    assert circuits.oracle_verify_batch(s, bad, I[:n], rand) == ref
+    for R in (2, 3, 4):
+        got = _sharded(ctx, bad, I[:n], rand, R)      # proof 19 sits on the last shard; shard 0 folds
+        assert got == ref, R
+    # and the fold still accepts the untampered batch
+    assert _sharded(ctx, P[:n], I[:n], rand, 3)[0] is True
     ctx.close()
 
 

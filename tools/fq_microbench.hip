@@ -3,8 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "curve.cuh"
-#include "pairing.cuh"
+#include "curve.hip.h"
+#include "pairing.hip.h"
 using namespace h2v;
 namespace h2v { void set_last_error(const std::string&) {} }
 

@@ -1,13 +1,13 @@
 // Micro-benchmark of the Fq Montgomery product with 9 x 29-bit limbs (product scanning, 64-bit column accumulators, no carry
 // chains) on gfx950: the prototype this file started as (mul29 / sqr29 / add29, kept here), the library's own Fq::mul_inl
-// (csrc/bn254.cuh adopted the prototype; the 8 x 32-bit CIOS product it replaced measured 1052 ns on a lone wave and
+// (csrc/bn254.hip.h adopted the prototype; the 8 x 32-bit CIOS product it replaced measured 1052 ns on a lone wave and
 // 83 G products/s chip-wide with this same harness), a two-accumulator variant (no gain: recorded negative result), and the
 // product rate as a function of occupancy (1, 2, 3 waves per SIMD) — the MSM kernels run at 2 waves per SIMD.
 // Build: hipcc -O3 --offload-arch=gfx950 -I halo2_verifier_amd/csrc tools/limb29_microbench.hip -o tools/limb29_microbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "curve.cuh"
+#include "curve.hip.h"
 using namespace h2v;
 namespace h2v { void set_last_error(const std::string&) {} }
 

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <string>
-#include "pairing.cuh"
+#include "pairing.hip.h"
 using namespace h2v;
 namespace h2v { void set_last_error(const std::string&) {} }
 
