@@ -48,8 +48,17 @@ namespace h2v {
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
-// lanes that share a window's bucket reduction: one wave up to 2048 buckets, four beyond
-static inline uint32_t msm_window_threads(uint32_t buckets) { return buckets <= 64 ? std::max(1u, buckets) : (buckets <= 2048 ? 64u : 256u); }
+// lanes that share a window's bucket reduction: one wave up to 2048 buckets, four beyond.  A window's reduction is a dependent
+// chain of 2 * slice + ~c + log2(T) group additions on every lane, so when the launch has few (problem, window) pairs — the
+// latency-bound case: one 20-step launch is 480 of them on 256 CUs — more lanes per window shorten the chain for free: four waves
+// while every workgroup still gets a CU of its own (108 KB of LDS each), two waves while two fit per CU.
+static inline uint32_t msm_window_threads(uint32_t buckets, uint32_t n_workgroups = 0xffffffffu) {
+    if (buckets <= 64) return std::max(1u, buckets);
+    if (n_workgroups != 0xffffffffu) { static const char* e = getenv("H2V_MSM_WIN_T"); if (e) return (uint32_t)atoi(e); }   // tuning knob
+    if (buckets > 2048 || (buckets >= 256 && n_workgroups <= 256)) return 256u;
+    if (buckets >= 128 && n_workgroups <= 512) return 128u;
+    return 64u;
+}
 
 // Window width.  Throughput plan: a cost model in Fq products — 2n mixed additions (11) per window, and per window the
 // reduction sum_b (b+1) B_b done by T lanes: 2 * slice running-sum additions, a c-bit double-and-add to weight the slice, a
@@ -601,7 +610,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
     {
-        const uint32_t T = msm_window_threads(p.buckets);
+        const uint32_t T = msm_window_threads(p.buckets, p.windows * count);
         const size_t win_lds = (size_t)(T > 64 ? 4 : 3) * T * sizeof(G1J);   // 20 KB for one wave, 108 KB for four
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
         hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(T), win_lds, s, ws.bucket_pts, ws.window_sums, p);

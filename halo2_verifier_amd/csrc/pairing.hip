@@ -1,19 +1,31 @@
 // Final pairing check kernel:  e(left, s_g2) * e(right, -g2) == 1  (DualMSM::check,
 // poly/kzg/msm.rs:185-203).
 //
-// One WAVE per check.  A pairing is a strictly sequential chain of ~480 Fq12 products (Miller loop over 6x+2,
-// then the final exponentiation); on a single lane that is ~20 000 dependent Fq products, and a batch ends with exactly
-// one of them.  Here an Fq12 element lives in LDS as six Fq2 coefficients of Fq2[w]/(w^6 - xi), and each product is spread
-// over the wave: a lane computes ONE coordinate of one a_i * b_j as a single-pass sum of two Fq products (the factor xi of
-// the pairs with i + j >= 6 is applied to the operand by an integer combination on the limbs), the partial products go
-// through LDS, and twelve lanes add six of them each.  No modular additions, no Karatsuba, no Montgomery pass in the fold.
+// A pairing is a strictly sequential chain of ~470 Fq12 operations (Miller loop over 6x+2, then the final
+// exponentiation); a batch ends with exactly one of them, so what counts is the LATENCY of one Fq12 operation.
+//
+// Two waves per check.  An Fq12 element lives in LDS as six Fq2 coefficients of Fq2[w]/(w^6 - xi), each stored with its
+// negated imaginary part alongside (c0, c1, -c1).  One product has two phases:
+//   products  lane (i, j, coordinate) computes ONE coordinate of a_i * b_j as a single-pass sum of two Fq products with one
+//             shared Montgomery reduction (Fp::dot2_inl):  re = a0 b0 + a1 (-b1),  im = a0 b1 + a1 b0 — the stored -c1 means
+//             no arithmetic at all comes before the multiply.  72 lanes for a general product, 42 for a squaring (the 21
+//             distinct a_i a_j), 60 for a product with a Miller line (its w^5 coefficient is zero): always ONE pass.
+//   fold      18 outputs, one per (coefficient, re / im / -im), three lanes each: plain limb sums of the partial products; the
+//             w^6 = xi = 9 + u reduction is applied HERE as integer weights on the sums (re: low + 9 hi_re - hi_im, im: low +
+//             9 hi_im + hi_re), brought below 2p by Fp::from_wide — no Montgomery pass, no modular additions.
+// Round 1 applied xi to an operand inside every product lane (two from_wide per lane: as many instructions as the multiply
+// itself) and ran through ~100 call sites with spills around each; here the whole pairing is a TABLE of ~470 operations
+// (built once per context on the host: Miller loop, easy part, the x-power chain of the hard part) interpreted by one loop
+// whose body holds a single inlined product and a single inlined fold.
 //
 // The G2 side is constant per context, so its Miller-loop line coefficients are precomputed once on the host
-// (g2_prepare); the wave evaluates them at the two G1 points up front, all lines in parallel, into LDS.
+// (g2_prepare); the lanes evaluate them at the two G1 points up front, all lines in parallel, into LDS.
 // The G1 points are used projectively (line values scaled by Z^3 in Fq*, which the final exponentiation kills),
-// so no field inversion is needed for them.
+// so no field inversion is needed for them.  The one inversion of the final exponentiation (f^-1 for f^(p^6 - 1)) descends
+// by norms: N = f conj(f) lies in Fq6, N^-1 = N^(p^2) N^(p^4) / Norm(N) with Norm(N) in Fq2 — four wave products and a single
+// Fq inversion on one lane.
 //
-// SingleStrategy (one check per proof) launches one such wave per proof.
+// SingleStrategy (one check per proof) launches one such workgroup per proof.
 #include "../../include/h2v.h"
 #include "internal.h"
 #include "pairing.hip.h"
@@ -21,215 +33,240 @@
 
 namespace h2v {
 
-#define N_LINES 102  // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
+#define N_LINES 102       // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
+#define PAIR_THREADS 128
+#define PAIR_REGS 10
+#define PAIR_MAX_OPS 512
 
-struct WaveShared {
-    // step i of the Miller loop multiplies f by l0_i(P0) * l1_i(P1).  The two sparse lines (coefficients of w^0, w^1, w^3,
-    // evaluated at their point) are written here first, then replaced in place by their 6-coefficient product.
-    Fq2 line[N_LINES][6];
-    Fq2 prod[36];
-    Fq2 f[6], r[6], t0[6], t1[6], t2[6], t3[6], t4[6], t5[6], t6[6];
-};
+enum PairOpCode : uint32_t { P_SQR = 1, P_MUL = 2, P_MULL = 3, P_CONJ = 4, P_FROB = 5, P_INV2 = 6, P_COPY = 7, P_CHECK = 8 };
+static inline uint32_t pair_op(uint32_t op, uint32_t d, uint32_t a, uint32_t b) { return op | (d << 8) | (a << 16) | (b << 24); }
 
-// The w^6 = xi = 9 + u reduction is applied to an OPERAND, not to the products: lane (i, j) with i + j >= 6 multiplies a_i by
-// xi * b_j = (9 b0 - b1) + (9 b1 + b0) u, an integer combination of two residues on the limbs brought below 2p by
-// Fp::from_wide (no Montgomery pass), so that every coefficient of the result is a PLAIN sum of six partial products.
-// (Computing xi * b once per product in a phase of its own was tried: the extra barrier costs more than the redundancy.)
-// One coordinate of the Fq2 product a * b (or a * xi b), one reduction pass (Fp::dot2_inl, result < 1.05p):
-//   real      = a0 * B0 + a1 * (-B1)        imaginary = a0 * B1 + a1 * B0        with (B0, B1) = b or xi b
-__device__ __noinline__ Fq fq2_mul_coord(Fq2 a, Fq2 b, uint32_t coord, bool times_xi) {
-    Fq s0, s1;
-    if (!times_xi) {
-        s0 = coord ? b.c1 : b.c0;
-        s1 = coord ? b.c0 : b.c1.neg();
-    } else {
-        // B0 = 9 b0 + (2p - b1);  B1 = 9 b1 + b0;  -B1 = 9 (2p - b1) + (2p - b0).  All positive, < 21p.
-        int64_t t0[9], t1[9];
-#pragma unroll
-        for (int l = 0; l < 9; ++l) {
-            const int64_t p2 = 2 * (int64_t)FqParams::P29(l), b0 = b.c0.v[l], b1 = b.c1.v[l];
-            const int64_t B0 = 9 * b0 + (p2 - b1), B1 = 9 * b1 + b0, nB1 = 9 * (p2 - b1) + (p2 - b0);
-            t0[l] = coord ? B1 : B0;
-            t1[l] = coord ? B0 : nB1;
-        }
-        s0 = Fq::from_wide(t0);
-        s1 = Fq::from_wide(t1);
-    }
-    return Fq::dot2_inl(a.c0, s0, a.c1, s1);
-}
-// One Fq coordinate of coefficient k of the product: the sum of the six partial products P_ij with i + j = k (mod 6) — the
-// xi factor already sits in the ones with i + j >= 6 — added on the limbs (six 29-bit limbs cannot overflow 32 bits) and
-// reduced below 2p by Fp::from_wide.
-__device__ __noinline__ Fq wfold_coord(const Fq2* __restrict__ prod, uint32_t k, uint32_t c) {
-    uint32_t sum[9];
-#pragma unroll
-    for (int l = 0; l < 9; ++l) sum[l] = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 6; ++i) {
-        const Fq2& P = prod[i * 6 + (i <= k ? k - i : k + 6 - i)];
-        const Fq& v = c ? P.c1 : P.c0;
-#pragma unroll
-        for (int l = 0; l < 9; ++l) sum[l] += v.v[l];
-    }
-    int64_t acc[9];
-#pragma unroll
-    for (int l = 0; l < 9; ++l) acc[l] = (int64_t)sum[l];
-    return Fq::from_wide(acc);
-}
-__device__ __forceinline__ void prod_store(Fq2* prod, uint32_t idx, uint32_t coord, const Fq& v) { if (coord) prod[idx].c1 = v; else prod[idx].c0 = v; }
-__device__ __forceinline__ void wfold(WaveShared& s, Fq2* dst, uint32_t lane) {
-    __syncthreads();
-    if (lane < 12) {
-        const Fq r = wfold_coord(s.prod, lane >> 1, lane & 1);
-        if (lane & 1) dst[lane >> 1].c1 = r; else dst[lane >> 1].c0 = r;
-    }
-    __syncthreads();
-}
-// dst = x * y in Fq2[w]/(w^6 - xi); dst may alias x or y.  36 lanes, two passes each.
-__device__ __forceinline__ void wmul(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {
-    if (lane < 36) {
-        const uint32_t i = lane / 6, j = lane % 6;
-        const Fq2 a = x[i], b = y[j];
-        s.prod[lane] = {fq2_mul_coord(a, b, 0, i + j >= 6), fq2_mul_coord(a, b, 1, i + j >= 6)};
-    }
-    wfold(s, dst, lane);
-}
-// dst = x^2: the 21 products a_i*a_j, i <= j, are each computed once — 42 lanes, ONE pass each — and stored at both (i, j) and (j, i)
-__device__ __forceinline__ void wsqr(WaveShared& s, Fq2* dst, const Fq2* x, uint32_t lane) {
-    if (lane < 42) {
-        const uint32_t pr = lane >> 1, coord = lane & 1;
-        // pair number -> (i, j), i <= j, rows of lengths 6, 5, 4, 3, 2, 1
-        uint32_t i = 0, r = pr;
-        while (r >= 6 - i) { r -= 6 - i; ++i; }
-        const uint32_t j = i + r;
-        const Fq v = fq2_mul_coord(x[i], x[j], coord, i + j >= 6);
-        prod_store(s.prod, i * 6 + j, coord, v);
-        prod_store(s.prod, j * 6 + i, coord, v);
-    }
-    wfold(s, dst, lane);
-}
-// dst = x * l for a line product l (coefficient of w^5 is zero): 30 Fq2 products, 60 lanes, ONE pass each
-__device__ __forceinline__ void wmul_line(WaveShared& s, Fq2* dst, const Fq2* x, const Fq2* l, uint32_t lane) {
-    if (lane < 60) {
-        const uint32_t pr = lane >> 1, coord = lane & 1, i = pr / 5, j = pr % 5;
-        prod_store(s.prod, i * 6 + j, coord, fq2_mul_coord(x[i], l[j], coord, i + j >= 6));
-    }
-    if (lane < 12) prod_store(s.prod, (lane >> 1) * 6 + 5, lane & 1, Fq::zero());
-    wfold(s, dst, lane);
-}
-__device__ __forceinline__ void wcopy(Fq2* dst, const Fq2* src, uint32_t lane) { if (lane < 6) dst[lane] = src[lane]; __syncthreads(); }
-// x -> x^(p^6): w -> -w
-__device__ __forceinline__ void wconj(Fq2* dst, const Fq2* src, uint32_t lane) { if (lane < 6) dst[lane] = (lane & 1) ? src[lane].neg() : src[lane]; __syncthreads(); }
-// x -> x^p
-__device__ __forceinline__ void wfrob(Fq2* dst, const Fq2* src, const PairingConsts* k, uint32_t lane) {
-    if (lane < 6) { Fq2 c = src[lane].conj(); dst[lane] = lane == 0 ? c : Fq2::mul(c, k->gamma1[lane]); }
-    __syncthreads();
-}
-// Inverse in the tower view f = c0 + c1 w, c0 = (a0, a2, a4), c1 = (a1, a3, a5) in Fq6 = Fq2[v]/(v^3 - xi), w^2 = v:
-// f^-1 = (c0 - c1 w) / N with N = f * (c0 - c1 w) = c0^2 - v c1^2 in Fq6 (only even powers of w).  The two products run on
-// the wave; only the Fq6 inversion (one Fq inversion inside) is left to a single lane.  n must hold N on entry and holds
-// N^-1 (as an element of the big field) on return.
-__device__ __noinline__ void winv6_lane0(Fq2* n) {
-    Fq6 t = {n[0], n[2], n[4]};
-    t = t.inv();
-    n[0] = t.c0; n[2] = t.c1; n[4] = t.c2;
-    n[1] = Fq2::zero(); n[3] = Fq2::zero(); n[5] = Fq2::zero();
-}
-// dst = x^BN_X (x in the cyclotomic subgroup); tmp is scratch; dst must not alias x
-__device__ __forceinline__ void wpow_x(WaveShared& s, Fq2* dst, const Fq2* x, uint32_t lane) {
-    wcopy(dst, x, lane);
-    for (int i = 61; i >= 0; --i) {
-        wsqr(s, dst, dst, lane);
-        if ((BN_X >> i) & 1) wmul(s, dst, dst, x, lane);
-    }
-}
-
-__global__ void __launch_bounds__(64) k_pairing_wave(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
-                                                     const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
-                                                     uint32_t* __restrict__ ok) {
-    __shared__ WaveShared s;
-    const uint32_t chk = blockIdx.x, lane = threadIdx.x;
-    if (chk >= n) return;
-    const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
-    const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
-    // line l(P) = a*y + b*x*w + c*w^3 with (x, y) = (X/Z^2, Y/Z^3); scaled by Z^3: a*Y + b*X*Z*w + c*Z^3*w^3
-    const Fq xz0 = P0.X * P0.Z, z30 = P0.Z.sqr() * P0.Z, xz1 = P1.X * P1.Z, z31 = P1.Z.sqr() * P1.Z;
-    for (uint32_t t = lane; t < 2 * N_LINES; t += 64) {
-        const uint32_t pr = t / N_LINES, li = t % N_LINES;
-        const LineCoeff c = pr ? l_ng2[li] : l_sg2[li];
-        s.line[li][3 * pr + 0] = c.a.scale(pr ? P1.Y : P0.Y);
-        s.line[li][3 * pr + 1] = c.b.scale(pr ? xz1 : xz0);
-        s.line[li][3 * pr + 2] = c.c.scale(pr ? z31 : z30);
-    }
-    if (lane < 6) s.f[lane] = lane == 0 ? Fq2::one() : Fq2::zero();
-    __syncthreads();
-    // all per-step line products up front, one lane per step, in place:
-    //   (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
-    // an identity point contributes the line value 1
-    for (uint32_t li = lane; li < N_LINES; li += 64) {
-        Fq2 a0 = s.line[li][0], b0 = s.line[li][1], c0 = s.line[li][2], a1 = s.line[li][3], b1 = s.line[li][4], c1 = s.line[li][5];
-        if (skip0) { a0 = Fq2::one(); b0 = Fq2::zero(); c0 = Fq2::zero(); }
-        if (skip1) { a1 = Fq2::one(); b1 = Fq2::zero(); c1 = Fq2::zero(); }
-        Fq2 a0a1 = a0 * a1, b0b1 = b0 * b1, c0c1 = c0 * c1;
-        Fq2 ab = (a0 + b0) * (a1 + b1) - a0a1 - b0b1;          // a0b1 + b0a1
-        Fq2 ac = (a0 + c0) * (a1 + c1) - a0a1 - c0c1;          // a0c1 + c0a1
-        Fq2 bc = (b0 + c0) * (b1 + c1) - b0b1 - c0c1;          // b0c1 + c0b1
-        s.line[li][0] = a0a1 + c0c1.mul_xi(); s.line[li][1] = ab; s.line[li][2] = b0b1; s.line[li][3] = ac; s.line[li][4] = bc; s.line[li][5] = Fq2::zero();
-    }
-    __syncthreads();
-    // Miller loop: one squaring and one product per doubling step, one more product per addition step
+// The operation table of one pairing check (host, once per context).  Registers: 0 = f, 1 = r, 2.. = temporaries.
+std::vector<uint32_t> pairing_program() {
+    std::vector<uint32_t> p;
+    enum { F = 0, R = 1, T0 = 2, T1 = 3, T2 = 4, T3 = 5, T4 = 6, T5 = 7, T6 = 8 };
+    auto sqr = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_SQR, d, a, 0)); };
+    auto mul = [&](uint32_t d, uint32_t a, uint32_t b) { p.push_back(pair_op(P_MUL, d, a, b)); };
+    auto conj = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_CONJ, d, a, 0)); };
+    auto frob = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_FROB, d, a, 0)); };
+    auto copy = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_COPY, d, a, 0)); };
+    // Miller loop: one squaring and one line product per doubling step, one more line product per addition step
     uint32_t idx = 0;
     for (int i = 63; i >= 0; --i) {
-        wsqr(s, s.f, s.f, lane);
-        wmul_line(s, s.f, s.f, s.line[idx++], lane);
-        if ((ATE_LOW >> i) & 1) wmul_line(s, s.f, s.f, s.line[idx++], lane);
+        sqr(F, F);
+        p.push_back(pair_op(P_MULL, F, F, idx++));
+        if ((ATE_LOW >> i) & 1) p.push_back(pair_op(P_MULL, F, F, idx++));
     }
-    wmul_line(s, s.f, s.f, s.line[idx++], lane);
-    wmul_line(s, s.f, s.f, s.line[idx++], lane);
+    p.push_back(pair_op(P_MULL, F, F, idx++));
+    p.push_back(pair_op(P_MULL, F, F, idx++));
     // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
-    wconj(s.t1, s.f, lane);                    // t1 = conj(f) = f^(p^6)
-    wmul(s, s.t2, s.f, s.t1, lane);            // N = f * conj(f), in Fq6
-    if (lane == 0) winv6_lane0(s.t2);
+    conj(T1, F);                       // conj(f) = f^(p^6)
+    mul(T2, F, T1);                    // N = f conj(f), in Fq6 (even powers of w)
+    frob(T3, T2); frob(T3, T3);        // N^(p^2)
+    frob(T4, T3); frob(T4, T4);        // N^(p^4)
+    mul(T3, T3, T4);                   // T = N^(p^2) N^(p^4)
+    mul(T4, T2, T3);                   // Norm(N) = N T, in Fq2 (coefficient 0)
+    p.push_back(pair_op(P_INV2, T4, T4, 0));
+    mul(T3, T3, T4);                   // N^-1
+    mul(T0, T1, T3);                   // f^-1
+    mul(R, T1, T0);                    // f^(p^6 - 1)
+    frob(T0, R); frob(T0, T0);
+    mul(R, T0, R);                     // ^(p^2 + 1)
+    // hard part: the x-power chain of Fuentes-Castaneda et al. (y0 .. y16); inverses in the cyclotomic subgroup are conjugates
+    auto pow_x = [&](uint32_t d, uint32_t a) {   // d = a^BN_X, d != a
+        copy(d, a);
+        for (int i = 61; i >= 0; --i) { sqr(d, d); if ((BN_X >> i) & 1) mul(d, d, a); }
+    };
+    const uint32_t y0 = T0, y1 = T1, y3 = T2, y4 = T3, y6 = T4, u = T5, v = T6;
+    pow_x(y0, R); conj(y0, y0);        // y0 = r^-x
+    sqr(y1, y0);                       // y1 = y0^2
+    sqr(u, y1);                        // y2 = y1^2
+    mul(y3, u, y1);                    // y3 = y2 y1
+    pow_x(y4, y3); conj(y4, y4);       // y4 = y3^-x
+    sqr(u, y4);                        // y5 = y4^2
+    pow_x(y6, u); conj(y6, y6);        // y6 = y5^-x
+    conj(y3, y3);
+    conj(y6, y6);
+    mul(u, y6, y4);                    // y7 = y6 y4
+    mul(u, u, y3);                     // y8 = y7 y3            (u = y8)
+    mul(v, u, y1);                     // y9 = y8 y1            (v = y9)
+    mul(y0, u, y4);                    // y10 = y8 y4
+    mul(y0, y0, R);                    // y11 = y10 r           (y0 = y11)
+    frob(y1, v);                       // y12 = y9^p
+    mul(y0, y1, y0);                   // y13 = y12 y11
+    frob(u, u); frob(u, u);            // y8^(p^2)
+    mul(y0, u, y0);                    // y14
+    conj(y1, R);
+    mul(y1, y1, v);                    // conj(r) y9
+    frob(y1, y1); frob(y1, y1); frob(y1, y1);   // y15
+    mul(y0, y1, y0);                   // y16
+    p.push_back(pair_op(P_CHECK, 0, y0, 0));
+    return p;
+}
+
+struct Coef { Fq c0, c1, n1; };   // an Fq2 coefficient and the negated imaginary part: n1 = -c1
+struct PairShared {
+    Fq2 line[N_LINES][5];         // per Miller step: l0(P0) * l1(P1), coefficients of w^0 .. w^4 (w^5 is zero)
+    Fq2 prod[36];                 // partial products a_i * b_j at [6 i + j]
+    Coef reg[PAIR_REGS][6];
+    uint32_t prog[PAIR_MAX_OPS];  // the operation table, copied once: one LDS broadcast read per operation instead of a memory load
+};
+
+// k-fold multiples of p on the limbs (offsets that keep the fold's integer combinations non-negative)
+__device__ __forceinline__ int64_t p_times(int l, int64_t k) { return k * (int64_t)FqParams::P29(l); }
+
+__global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
+                                                          const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
+                                                          const uint32_t* __restrict__ prog, uint32_t n_ops, uint32_t* __restrict__ ok) {
+    __shared__ PairShared s;
+    const uint32_t chk = blockIdx.x, t = threadIdx.x;
+    if (chk >= n) return;
+    {
+        const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
+        const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
+        // line l(P) = a*y + b*x*w + c*w^3 with (x, y) = (X/Z^2, Y/Z^3); scaled by Z^3: a*Y + b*X*Z*w + c*Z^3*w^3
+        const Fq xz0 = P0.X * P0.Z, z30 = P0.Z.sqr() * P0.Z, xz1 = P1.X * P1.Z, z31 = P1.Z.sqr() * P1.Z;
+        for (uint32_t li = t; li < N_LINES; li += PAIR_THREADS) {
+            const LineCoeff q0 = l_sg2[li], q1 = l_ng2[li];
+            Fq2 a0 = q0.a.scale(P0.Y), b0 = q0.b.scale(xz0), c0 = q0.c.scale(z30);
+            Fq2 a1 = q1.a.scale(P1.Y), b1 = q1.b.scale(xz1), c1 = q1.c.scale(z31);
+            // an identity point contributes the line value 1
+            if (skip0) { a0 = Fq2::one(); b0 = Fq2::zero(); c0 = Fq2::zero(); }
+            if (skip1) { a1 = Fq2::one(); b1 = Fq2::zero(); c1 = Fq2::zero(); }
+            // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
+            Fq2 a0a1 = a0 * a1, b0b1 = b0 * b1, c0c1 = c0 * c1;
+            Fq2 ab = (a0 + b0) * (a1 + b1) - a0a1 - b0b1;
+            Fq2 ac = (a0 + c0) * (a1 + c1) - a0a1 - c0c1;
+            Fq2 bc = (b0 + c0) * (b1 + c1) - b0b1 - c0c1;
+            s.line[li][0] = a0a1 + c0c1.mul_xi(); s.line[li][1] = ab; s.line[li][2] = b0b1; s.line[li][3] = ac; s.line[li][4] = bc;
+        }
+        if (t < 6) {
+            Coef c; c.c0 = t == 0 ? Fq::one() : Fq::zero(); c.c1 = Fq::zero(); c.n1 = Fq::zero();
+            s.reg[0][t] = c;
+        }
+        for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
+    }
     __syncthreads();
-    wmul(s, s.t0, s.t1, s.t2, lane);           // f^-1
-    wmul(s, s.r, s.t1, s.t0, lane);            // f^(p^6 - 1)
-    wfrob(s.t0, s.r, consts, lane);
-    wfrob(s.t0, s.t0, consts, lane);
-    wmul(s, s.r, s.t0, s.r, lane);             // ^(p^2 + 1)
-    // hard part: the x-power chain of Fuentes-Castaneda et al. (y0 .. y16)
-    Fq2 *y0 = s.t0, *y1 = s.t1, *y3 = s.t2, *y4 = s.t3, *y6 = s.t4, *u = s.t5, *v = s.t6;
-    wpow_x(s, y0, s.r, lane); wconj(y0, y0, lane);               // y0 = r^-x
-    wsqr(s, y1, y0, lane);                                       // y1 = y0^2
-    wsqr(s, u, y1, lane);                                        // y2 = y1^2
-    wmul(s, y3, u, y1, lane);                                    // y3 = y2 * y1
-    wpow_x(s, y4, y3, lane); wconj(y4, y4, lane);                // y4 = y3^-x
-    wsqr(s, u, y4, lane);                                        // y5 = y4^2
-    wpow_x(s, y6, u, lane); wconj(y6, y6, lane);                 // y6 = y5^-x
-    wconj(y3, y3, lane);
-    wconj(y6, y6, lane);
-    wmul(s, u, y6, y4, lane);                                    // y7 = y6 * y4
-    wmul(s, u, u, y3, lane);                                     // y8 = y7 * y3          (u = y8)
-    wmul(s, v, u, y1, lane);                                     // y9 = y8 * y1          (v = y9)
-    wmul(s, y0, u, y4, lane);                                    // y10 = y8 * y4
-    wmul(s, y0, y0, s.r, lane);                                  // y11 = y10 * r         (y0 = y11)
-    wfrob(y1, v, consts, lane);                                  // y12 = y9^p
-    wmul(s, y0, y1, y0, lane);                                   // y13 = y12 * y11       (y0 = y13)
-    wfrob(u, u, consts, lane); wfrob(u, u, consts, lane);        // y8^(p^2)
-    wmul(s, y0, u, y0, lane);                                    // y14 = y8' * y13       (y0 = y14)
-    wconj(y1, s.r, lane);
-    wmul(s, y1, y1, v, lane);                                    // conj(r) * y9
-    wfrob(y1, y1, consts, lane); wfrob(y1, y1, consts, lane); wfrob(y1, y1, consts, lane);  // y15
-    wmul(s, y0, y1, y0, lane);                                   // y16 = y15 * y14
-    if (lane == 0) {
-        bool one = y0[0] == Fq2::one();
-        for (int k2 = 1; k2 < 6; ++k2) one = one && y0[k2].is_zero();
-        ok[chk] = one ? 1u : 0u;
+    for (uint32_t pc = 0; pc < n_ops; ++pc) {
+        const uint32_t w = s.prog[pc];   // uniform
+        const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
+        if (op <= P_MULL) {
+            // ---- products: one dot2 per lane
+            const uint32_t pr = t >> 1, coord = t & 1u;
+            uint32_t i = 0, j = 0;
+            bool active;
+            const Fq *a0, *a1;        // the factor that needs no negation
+            const Coef* bb;           // the factor whose -c1 is stored
+            if (op == P_SQR) {
+                active = t < 42;
+                // pair number -> (i, j), i <= j, rows of lengths 6, 5, 4, 3, 2, 1
+                uint32_t base = 0;
+                i = pr >= 6 ? 1 : 0; base = pr >= 6 ? 6 : 0;
+                if (pr >= 11) { i = 2; base = 11; }
+                if (pr >= 15) { i = 3; base = 15; }
+                if (pr >= 18) { i = 4; base = 18; }
+                if (pr >= 20) { i = 5; base = 20; }
+                j = i + (pr - base);
+                if (!active) { i = 0; j = 0; }
+                a0 = &s.reg[ra][i].c0; a1 = &s.reg[ra][i].c1; bb = &s.reg[ra][j];
+            } else if (op == P_MUL) {
+                active = t < 72;
+                i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;
+                a0 = &s.reg[ra][i].c0; a1 = &s.reg[ra][i].c1; bb = &s.reg[rb][j];
+            } else {
+                active = t < 60;
+                i = active ? pr / 5 : 0; j = active ? pr % 5 : 0;     // x_i * l_j
+                a0 = &s.line[rb][j].c0; a1 = &s.line[rb][j].c1; bb = &s.reg[ra][i];
+            }
+            if (active) {
+                const Fq A0 = *a0, A1 = *a1;
+                const Fq B0 = coord ? bb->c1 : bb->c0, B1 = coord ? bb->c0 : bb->n1;
+                const Fq r = Fq::dot2_inl(A0, B0, A1, B1);
+                Fq* dst = coord ? &s.prod[i * 6 + j].c1 : &s.prod[i * 6 + j].c0;
+                *dst = r;
+                if (op == P_SQR && i != j) { Fq* d2 = coord ? &s.prod[j * 6 + i].c1 : &s.prod[j * 6 + i].c0; *d2 = r; }
+            } else if (op == P_MULL && t < 72) {
+                // the line's w^5 coefficient is zero: lanes 60..71 clear the six products x_i * l_5
+                const uint32_t q = t - 60;
+                Fq* dst = (q & 1u) ? &s.prod[(q >> 1) * 6 + 5].c1 : &s.prod[(q >> 1) * 6 + 5].c0;
+                *dst = Fq::zero();
+            }
+            __syncthreads();
+            // ---- fold: 18 outputs (coefficient k, kind 0 = re / 1 = im / 2 = -im), a quad of lanes each.  Lane 0 of the quad sums
+            // the partial products with i + j = k ("low"), lane 1 those with i + j = k + 6 in the output's own coordinate, lane 2
+            // the same entries in the other coordinate; lane 0 then collects the three sums (DPP quad broadcasts), applies
+            // w^6 = xi = 9 + u as integer weights and reduces once.  One lane per output did all three sums one after the other —
+            // twice the instructions on the critical path.
+            if (t < 72) {
+                const uint32_t o = t >> 2, role = t & 3u, k = o % 6, kind = o / 6;
+                const bool im = kind != 0;
+                // a_i b_j with i + j = k sits at entry k + 5 i (i <= k); with i + j = k + 6 at entry k + 6 + 5 i (i > k)
+                const bool same = role != 2;                           // which coordinate of the entry this lane adds up
+                const uint32_t first = role == 0 ? 0 : k + 1, last = role == 0 ? k + 1 : (role == 3 ? 0 : 6);
+                const Fq2* e = &s.prod[k + 5 * first + (role == 0 ? 0 : 6)];
+                const Fq* q = (im == same) ? &e->c1 : &e->c0;
+                uint32_t sum[9];
+#pragma unroll
+                for (int l = 0; l < 9; ++l) sum[l] = 0;
+                for (uint32_t ii = first; ii < last; ++ii, q += 10) {   // 10 Fq = 5 entries
+#pragma unroll
+                    for (int l = 0; l < 9; ++l) sum[l] += q->v[l];
+                }
+                // partial products are < 1.05p: re = lo + 9 hs - ho + 6p in (0, 60p); im = lo + 9 hs + ho < 59p; -im = 60p - im
+                int64_t acc[9];
+#pragma unroll
+                for (int l = 0; l < 9; ++l) {
+                    const uint32_t hs = (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[l], 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
+                    const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[l], 0xaa, 0xf, 0xf, true);   // quad_perm [2,2,2,2]
+                    const int64_t pos = (int64_t)sum[l] + 9 * (int64_t)hs;
+                    if (kind == 0) acc[l] = pos - (int64_t)ho + p_times(l, 6);
+                    else if (kind == 1) acc[l] = pos + (int64_t)ho;
+                    else acc[l] = p_times(l, 60) - pos - (int64_t)ho;
+                }
+                if (role == 0) {
+                    const Fq r = Fq::from_wide(acc);
+                    Coef* dst = &s.reg[rd][k];
+                    if (kind == 0) dst->c0 = r; else if (kind == 1) dst->c1 = r; else dst->n1 = r;
+                }
+            }
+            __syncthreads();
+        } else if (op == P_CHECK) {
+            if (t == 0) {
+                bool one = s.reg[ra][0].c0 == Fq::one() && s.reg[ra][0].c1.is_zero();
+                for (int k2 = 1; k2 < 6; ++k2) one = one && s.reg[ra][k2].c0.is_zero() && s.reg[ra][k2].c1.is_zero();
+                ok[chk] = one ? 1u : 0u;
+            }
+        } else {
+            // ---- coefficient-wise operations, one lane per coefficient
+            if (t < 6) {
+                const Coef x = s.reg[ra][t];
+                Coef r = x;
+                if (op == P_CONJ) {            // x^(p^6): w -> -w
+                    if (t & 1u) { r.c0 = x.c0.neg(); r.c1 = x.n1; r.n1 = x.c1; }
+                } else if (op == P_FROB) {     // x^p: conjugate every coefficient, times gamma^k
+                    if (t == 0) { r.c1 = x.n1; r.n1 = x.c1; }
+                    else {
+                        const Fq2 m = Fq2::mul(Fq2{x.c0, x.n1}, consts->gamma1[t]);
+                        r.c0 = m.c0; r.c1 = m.c1; r.n1 = m.c1.neg();
+                    }
+                } else if (op == P_INV2) {     // coefficient 0 <- its inverse in Fq2, the others <- 0
+                    if (t == 0) {
+                        const Fq nrm = x.c0.sqr() + x.c1.sqr();
+                        const Fq ni = nrm.inv();
+                        r.c0 = x.c0 * ni; r.c1 = x.n1 * ni; r.n1 = r.c1.neg();
+                    } else { r.c0 = Fq::zero(); r.c1 = Fq::zero(); r.n1 = Fq::zero(); }
+                }
+                s.reg[rd][t] = r;              // P_COPY: r = x
+            }
+            __syncthreads();
+        }
     }
 }
 
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_pairing_wave, dim3(n), dim3(64), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, d_ok);
+    if (!pd.prog || pd.n_ops > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
+    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -14,11 +14,14 @@ struct ParamsHost {
 bool params_from_bytes(const uint8_t* data, size_t len, int format, ParamsHost& out, std::string& err);
 
 PairingConsts pairing_consts_host();
+std::vector<uint32_t> pairing_program();
 
 struct PairingDevice {
     LineCoeff* l_sg2 = nullptr;  // line coefficients for s_g2
     LineCoeff* l_ng2 = nullptr;  // line coefficients for -g2
     PairingConsts* consts = nullptr;
+    uint32_t* prog = nullptr;    // the pairing's operation table (pairing.hip: pairing_program)
+    uint32_t n_ops = 0;
     int upload(const ParamsHost& p);
     void release();
 };

@@ -127,13 +127,18 @@ int PairingDevice::upload(const ParamsHost& p) {
     H2V_HIP_CHECK(hipMemcpy(l_sg2, a.data(), sizeof(LineCoeff) * na, hipMemcpyHostToDevice));
     H2V_HIP_CHECK(hipMemcpy(l_ng2, b.data(), sizeof(LineCoeff) * na, hipMemcpyHostToDevice));
     H2V_HIP_CHECK(hipMemcpy(consts, &k, sizeof(PairingConsts), hipMemcpyHostToDevice));
+    const std::vector<uint32_t> ops = pairing_program();
+    n_ops = (uint32_t)ops.size();
+    H2V_HIP_CHECK(hipMalloc(&prog, 4 * ops.size()));
+    H2V_HIP_CHECK(hipMemcpy(prog, ops.data(), 4 * ops.size(), hipMemcpyHostToDevice));
     return 0;
 }
 void PairingDevice::release() {
     if (l_sg2) hipFree(l_sg2);
     if (l_ng2) hipFree(l_ng2);
     if (consts) hipFree(consts);
-    l_sg2 = l_ng2 = nullptr; consts = nullptr;
+    if (prog) hipFree(prog);
+    l_sg2 = l_ng2 = nullptr; consts = nullptr; prog = nullptr; n_ops = 0;
 }
 
 }  // namespace h2v

@@ -422,7 +422,7 @@ class Batch:
         ok = ctypes.c_int(0)
         left, right = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
         check(self._lib.h2v_batch_finish(self._h, st, ctypes.byref(ok), left, right))
-        return bool(ok.value), list(st)[:self.n], left.raw, right.raw
+        return bool(ok.value), memoryview(st).cast('B').cast('i').tolist()[:self.n], left.raw, right.raw
 
     def finish_groups(self):
         """-> (group_ok[groups], statuses, left_xy[groups], right_xy[groups])"""
@@ -431,8 +431,9 @@ class Batch:
         ok = (ctypes.c_int * g)()
         left, right = ctypes.create_string_buffer(64 * g), ctypes.create_string_buffer(64 * g)
         check(self._lib.h2v_batch_finish_groups(self._h, st, ok, left, right, g))
-        return ([bool(v) for v in ok], list(st)[:self.n], [left.raw[64 * i:64 * i + 64] for i in range(g)],
-                [right.raw[64 * i:64 * i + 64] for i in range(g)])
+        lr, rr = left.raw, right.raw
+        return ([bool(v) for v in ok], memoryview(st).cast('B').cast('i').tolist()[:self.n], [lr[64 * i:64 * i + 64] for i in range(g)],
+                [rr[64 * i:64 * i + 64] for i in range(g)])
 
     def set_profiling(self, on=True):
         check(self._lib.h2v_batch_set_profiling(self._h, 1 if on else 0))

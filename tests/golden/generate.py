@@ -80,7 +80,29 @@ def case(name, s, proofs, rand_seed, notes):
     print(name, [e["single_status"] for e in out["proofs"]], out["batch"]["ok"])
 
 
+ONLY = set(sys.argv[1:])   # python tests/golden/generate.py [case name ...] regenerates only those files
+
+
 def main():
+    global case
+    if ONLY:
+        full_case = case
+
+        def case(name, *a, **kw):  # noqa: F811
+            if name in ONLY:
+                full_case(name, *a, **kw)
+    if not ONLY or "wide_k16_lookup_heavy" in ONLY:
+        # 6. BASELINE.json config 4: lookup-heavy VK with many advice / fixed columns at k = 16 (32 advice, 16 fixed, 8 two-column
+        #    lookups, degree-5 gates; 7.8 KB proofs, 124-term Guard).  Pins omega(k=16) (poly/domain.rs:52-72) and the whole
+        #    expression path at the configuration as stated.  ~70 s per proof for the test prover (2^19-point coset FFTs).
+        s = circuits.setup_wide(16, A=32, F=16, L_=8, Sh=0, deg=5)
+        good, inst = circuits.prove_wide(s, witness_seed=16)
+        bad, inst_b = circuits.prove_wide(s, witness_seed=16, tamper=True)
+        case("wide_k16_lookup_heavy", s, [("valid", good, inst), ("lookup_input_not_in_table", bad, inst_b)], 8,
+             "k=16, 32 advice, 16 fixed, 8 lookups (2-column), degree 5; second proof violates a lookup")
+        s.free()
+        if ONLY == {"wide_k16_lookup_heavy"}:
+            return
     # 1. the reference's vector_mul test (tests/vector_mul.rs:297-333) on the reference's own SRS file
     s = circuits.setup_vector_mul(8, 10, use_reference_srs=True)
     good, inst = circuits.prove_vector_mul(s, [2] * 10, [3] * 10, rng_seed=0)
