@@ -69,7 +69,7 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult);
 // out[i] = src[idx[i]]: the multipliers of a non-contiguous subset of a larger accumulation
 int gather_multipliers_enqueue(hipStream_t s, const Fr* d_src, const uint32_t* d_idx, uint32_t n, Fr* d_out);
-int frvm_enqueue(hipStream_t s, const FrvmArgs& a);
+int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal);
 }  // namespace h2v
 
@@ -77,6 +77,8 @@ struct h2v_batch {
     h2v_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
+    hipStream_t aux = nullptr;        // the accumulators' affine conversion runs here, beside the pairing (both only read them)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t max_proofs = 0, max_inst = 0;
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
     uint32_t n = 0, n_tail = 0;

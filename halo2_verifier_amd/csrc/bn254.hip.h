@@ -98,6 +98,131 @@ struct FrParams {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Modular inversion by "safegcd" divsteps (Bernstein-Yang 2019, in the constant-time formulation with signed 30-bit limbs
+// that Wuille's proof-carrying implementation made standard): d, e, f, g start as 0, 1, p, x; one batch of 30 divsteps looks
+// only at the low 30 bits of f and g and yields a 2 x 2 integer matrix t with [f, g] <- t [f, g] / 2^30 (exact) and
+// [d, e] <- t [d, e] / 2^30 mod p; 590 divsteps bring any 256-bit g to 0, f to +-1 and d to +-x^-1 (20 batches = 600 here).
+// Every step is branch-free and identical for all inputs — exactly what a wave wants: ~15 000 integer instructions for one
+// inverse, against ~75 000 for the Fermat chain x^(p-2) (253 squarings + 64 products).  Inverses sit on the critical path of
+// every latency-bound kernel (the Fr program's one batched inversion, the pairing's final exponentiation, the affine
+// conversion of the accumulators).  inv(0) = 0.
+struct Signed30 { int32_t v[9]; };   // value = sum v[i] 2^(30 i), limbs in (-2^30, 2^30)
+template <class PR> struct ModInv30 {
+    static constexpr int32_t M30 = (int32_t)(0xffffffffu >> 2);
+    // p as 30-bit limbs, from the 32-bit words
+    H2V_HD static constexpr int32_t P30(int i) {
+        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+        if (w >= 8) return 0;
+        uint64_t x = (uint64_t)PR::P(w) >> sh;
+        if (w + 1 < 8) x |= (uint64_t)PR::P(w + 1) << (32 - sh);
+        return (int32_t)(x & (uint64_t)M30);
+    }
+    // p^-1 mod 2^30 (Newton iteration on the low word; p is odd)
+    H2V_HD static constexpr uint32_t PINV30() {
+        uint32_t p0 = PR::P(0), x = p0;            // correct to 3 bits
+        for (int i = 0; i < 5; ++i) x *= 2u - p0 * x;
+        return x & (uint32_t)M30;
+    }
+    struct Trans { int32_t u, v, q, r; };
+    // 30 divsteps on the low limbs; zeta = -(delta + 1/2)
+    H2V_HD static int32_t divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, Trans& t) {
+        uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll
+        for (int i = 0; i < 30; ++i) {
+            uint32_t mask1 = (uint32_t)(zeta >> 31);          // zeta < 0
+            const uint32_t mask2 = 0u - (g & 1u);             // g odd
+            const uint32_t x = (f ^ mask1) - mask1, y = (u ^ mask1) - mask1, z = (v ^ mask1) - mask1;   // conditionally negated f, u, v
+            g += x & mask2; q += y & mask2; r += z & mask2;
+            mask1 &= mask2;
+            zeta = (int32_t)((uint32_t)zeta ^ mask1) - 1;     // -zeta - 2 or zeta - 1
+            f += g & mask1; u += q & mask1; v += r & mask1;
+            g >>= 1; u <<= 1; v <<= 1;
+        }
+        t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+        return zeta;
+    }
+    // [d, e] <- t [d, e] / 2^30 mod p, keeping both in (-2p, p)
+    H2V_HD static void update_de(Signed30& d, Signed30& e, const Trans& t) {
+        const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
+        const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+        int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+        int32_t di = d.v[0], ei = e.v[0];
+        int64_t cd = (int64_t)u * di + (int64_t)v * ei, ce = (int64_t)q * di + (int64_t)r * ei;
+        // choose md, me so that t [d, e] + p [md, me] has 30 zero bottom bits
+        md -= (int32_t)((PINV30() * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+        me -= (int32_t)((PINV30() * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+        cd += (int64_t)P30(0) * md; ce += (int64_t)P30(0) * me;
+        cd >>= 30; ce >>= 30;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            di = d.v[i]; ei = e.v[i];
+            cd += (int64_t)u * di + (int64_t)v * ei; ce += (int64_t)q * di + (int64_t)r * ei;
+            cd += (int64_t)P30(i) * md; ce += (int64_t)P30(i) * me;
+            d.v[i - 1] = (int32_t)cd & M30; cd >>= 30;
+            e.v[i - 1] = (int32_t)ce & M30; ce >>= 30;
+        }
+        d.v[8] = (int32_t)cd; e.v[8] = (int32_t)ce;
+    }
+    // [f, g] <- t [f, g] / 2^30 (the bottom 30 bits are zero by construction of t)
+    H2V_HD static void update_fg(Signed30& f, Signed30& g, const Trans& t) {
+        const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
+        int32_t fi = f.v[0], gi = g.v[0];
+        int64_t cf = (int64_t)u * fi + (int64_t)v * gi, cg = (int64_t)q * fi + (int64_t)r * gi;
+        cf >>= 30; cg >>= 30;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            fi = f.v[i]; gi = g.v[i];
+            cf += (int64_t)u * fi + (int64_t)v * gi; cg += (int64_t)q * fi + (int64_t)r * gi;
+            f.v[i - 1] = (int32_t)cf & M30; cf >>= 30;
+            g.v[i - 1] = (int32_t)cg & M30; cg >>= 30;
+        }
+        f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
+    }
+    // r in (-2p, p), negated if sign < 0, brought to [0, p)
+    H2V_HD static void normalize(Signed30& r, int32_t sign) {
+        int32_t cond_add = r.v[8] >> 31;
+        const int32_t cond_negate = sign >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { r.v[i] += P30(i) & cond_add; r.v[i] = (r.v[i] ^ cond_negate) - cond_negate; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { r.v[i + 1] += r.v[i] >> 30; r.v[i] &= M30; }
+        cond_add = r.v[8] >> 31;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.v[i] += P30(i) & cond_add;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { r.v[i + 1] += r.v[i] >> 30; r.v[i] &= M30; }
+    }
+    // x (canonical integer < p, 8 words) -> x^-1 mod p (8 words); 0 -> 0
+    H2V_FN static void invert(const uint32_t x[8], uint32_t out[8]) {
+        Signed30 d, e, f, g;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+            uint64_t t = w < 8 ? (uint64_t)x[w] >> sh : 0;
+            if (w + 1 < 8) t |= (uint64_t)x[w + 1] << (32 - sh);
+            g.v[i] = (int32_t)(t & (uint64_t)M30);
+            f.v[i] = P30(i); d.v[i] = 0; e.v[i] = i == 0 ? 1 : 0;
+        }
+        int32_t zeta = -1;
+        for (int it = 0; it < 20; ++it) {
+            Trans t;
+            zeta = divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+            update_de(d, e, t);
+            update_fg(f, g, t);
+        }
+        normalize(d, f.v[8]);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int bit = 32 * w, i = bit / 30, sh = bit % 30;
+            uint64_t t = (uint64_t)(uint32_t)d.v[i] >> sh;
+            if (i + 1 < 9) t |= (uint64_t)(uint32_t)d.v[i + 1] << (30 - sh);
+            if (i + 2 < 9 && 60 - sh < 32) t |= (uint64_t)(uint32_t)d.v[i + 2] << (60 - sh);
+            out[w] = (uint32_t)t;
+        }
+    }
+};
+
 template <class PR> struct Fp {
     uint32_t v[H2V_LIMBS];  // 29-bit limbs of a representative in [0, 2p) of (value * R) mod p
 
@@ -384,7 +509,17 @@ template <class PR> struct Fp {
         e[0] -= 2;  // p is odd and its low limb is >= 2 for both fields
         return pow_limbs(e);
     }
-    H2V_HD Fp inv() const { return inv_fermat(); }
+    // Inverse by safegcd divsteps (ModInv30 above).  The value held is a = x R; a^-1 = x^-1 R^-1 as a plain integer; one Montgomery
+    // product with R^3 brings it back: x^-1 R^-1 R^3 / R = x^-1 R.
+    H2V_FN Fp inv_safegcd() const {
+        uint32_t c[9], raw[8], o[8];
+        canonical(c);
+        unpack29(raw, c);
+        ModInv30<PR>::invert(raw, o);
+        Fp t; pack29(t.v, o);
+        return mul(t, mul(r2(), r2()));
+    }
+    H2V_HD Fp inv() const { return inv_safegcd(); }
     H2V_HD bool is_odd() const { uint32_t raw[8]; to_raw(raw); return raw[0] & 1; }
 };
 

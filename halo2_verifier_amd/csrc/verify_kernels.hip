@@ -15,6 +15,7 @@
 // program slots [slot][proof], shared scalars [j][proof].
 #include "../../include/h2v.h"
 #include "batch.h"
+#include <atomic>
 
 namespace h2v {
 
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(INSTEVAL_THREADS) k_instance_eval(InstEvalArgs
         }
         w = wc;                                                  // start of the thread's next chunk
         if (run.is_zero()) { zero_den = true; continue; }
-        Fr inv = run.inv_fermat();
+        Fr inv = run.inv();
         // backward: 1/d_c = inv * prefix_c, then inv *= d_c; omega^(j-rot) steps back by omega^-256
         for (uint32_t c = cnt; c-- > 0;) {
             wc = wc * a.omega_step_inv;
@@ -315,86 +316,102 @@ __global__ void __launch_bounds__(INSTEVAL_THREADS) k_instance_eval(InstEvalArgs
     }
 }
 
-// program slots are limb-planar: limb l of slot s of proof p is word (s * 9 + l) * n + p, so that a wave's 64 proofs read 64
-// consecutive words per limb
-__device__ __forceinline__ Fr slot_load(const Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p) {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(slots) + (size_t)s * H2V_LIMBS * n + p;
-    Fr r;
-#pragma unroll
-    for (int l = 0; l < H2V_LIMBS; ++l) r.v[l] = q[(size_t)l * n];
-    return r;
-}
-__device__ __forceinline__ void slot_store(Fr* __restrict__ slots, uint32_t s, uint32_t n, uint32_t p, const Fr& v) {
-    uint32_t* q = reinterpret_cast<uint32_t*>(slots) + (size_t)s * H2V_LIMBS * n + p;
-#pragma unroll
-    for (int l = 0; l < H2V_LIMBS; ++l) q[(size_t)l * n] = v.v[l];
+// Program slots.  The hottest ones (the lowest numbers: the allocator hands out freed slots last-in first-out) live in LDS,
+// [slot][limb][lane]; the rest are limb-planar in global memory: limb l of slot s of proof p is word (s * 9 + l) * n + p, so that
+// a wave's 64 proofs read 64 consecutive words per limb.  Round 1 kept every slot in global memory: each of the ~600
+// instructions of a program waited for two L2 round trips before its ~0.5 us of arithmetic.
+// a 32-byte little-endian scalar -> Fr (zero when not canonical).  Proof scalars and instance values sit at multiples of 32
+// bytes inside records whose length is a multiple of 32, in hipMalloc'ed buffers: two 16-byte loads instead of 32 byte loads.
+__device__ __forceinline__ Fr fr_from_le32(const uint8_t* b) {
+    const uint4 lo = reinterpret_cast<const uint4*>(b)[0], hi = reinterpret_cast<const uint4*>(b)[1];
+    const uint32_t raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (Fr::geq_p(raw)) return Fr::zero();
+    return Fr::from_raw(raw);
 }
 
-__global__ void __launch_bounds__(64) k_frvm(FrvmArgs a) {
+struct SlotFile {
+    uint32_t* lds; uint32_t lds_slots;
+    Fr* glob; uint32_t n, p, lane;
+    __device__ __forceinline__ Fr load(uint32_t s) const {
+        Fr r;
+        if (s < lds_slots) {
+            const uint32_t* q = lds + (size_t)s * H2V_LIMBS * 64 + lane;
+#pragma unroll
+            for (int l = 0; l < H2V_LIMBS; ++l) r.v[l] = q[l * 64];
+        } else {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(glob) + (size_t)s * H2V_LIMBS * n + p;
+#pragma unroll
+            for (int l = 0; l < H2V_LIMBS; ++l) r.v[l] = q[(size_t)l * n];
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(uint32_t s, const Fr& v) const {
+        if (s < lds_slots) {
+            uint32_t* q = lds + (size_t)s * H2V_LIMBS * 64 + lane;
+#pragma unroll
+            for (int l = 0; l < H2V_LIMBS; ++l) q[l * 64] = v.v[l];
+        } else {
+            uint32_t* q = reinterpret_cast<uint32_t*>(glob) + (size_t)s * H2V_LIMBS * n + p;
+#pragma unroll
+            for (int l = 0; l < H2V_LIMBS; ++l) q[(size_t)l * n] = v.v[l];
+        }
+    }
+};
+
+__global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
+    extern __shared__ uint32_t frvm_lds[];
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n) return;
     const uint32_t n = a.n;
+    const SlotFile sf{frvm_lds, lds_slots, a.slots, n, p, threadIdx.x};
+    // an operand of MUL / ADD / SUB is a slot or (VM_CONST_OPERAND) a program constant, read with uniform loads
+    auto opnd = [&](uint32_t x) -> Fr { return (x & VM_CONST_OPERAND) ? a.consts[x & ~VM_CONST_OPERAND] : sf.load(x); };
+    VmInstr nx = a.code[0];
     for (uint32_t pc = 0; pc < a.n_code; ++pc) {
-        const VmInstr in = a.code[pc];  // wave-uniform
+        const VmInstr in = nx;  // wave-uniform; the next instruction is fetched while this one executes
+        nx = a.code[pc + 1 < a.n_code ? pc + 1 : pc];
         switch (in.op) {
-            case OP_CONST: slot_store(a.slots, in.d, n, p, a.consts[in.a]); break;
-            case OP_MUL: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p) * slot_load(a.slots, in.b, n, p)); break;
-            case OP_ADD: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p) + slot_load(a.slots, in.b, n, p)); break;
-            case OP_SUB: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p) - slot_load(a.slots, in.b, n, p)); break;
-            case OP_NEG: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p).neg()); break;
+            case OP_CONST: sf.store(in.d, a.consts[in.a]); break;
+            case OP_MUL: sf.store(in.d, Fr::mul_inl(opnd(in.a), opnd(in.b))); break;
+            case OP_ADD: sf.store(in.d, opnd(in.a) + opnd(in.b)); break;
+            case OP_SUB: sf.store(in.d, opnd(in.a) - opnd(in.b)); break;
+            case OP_NEG: sf.store(in.d, sf.load(in.a).neg()); break;
             case OP_INV: {
-                Fr v = slot_load(a.slots, in.a, n, p);
+                Fr v = sf.load(in.a);
                 if (v.is_zero()) status_set(a.status, p, H2V_DEV_ST_PANIC);
-                // all lanes invert at once: the fixed-exponent chain is uniform across the wave, unlike the data-dependent
-                // steps of the binary-GCD inverse, which a lone lane (affine conversion, pairing) prefers
-                slot_store(a.slots, in.d, n, p, v.inv_fermat());
+                // all lanes invert at once: the divsteps of Fp::inv are branch-free, so the wave stays uniform
+                sf.store(in.d, v.inv());
                 break;
             }
-            case OP_POW: slot_store(a.slots, in.d, n, p, slot_load(a.slots, in.a, n, p).pow_u32(in.b)); break;
+            case OP_POW: sf.store(in.d, sf.load(in.a).pow_u32(in.b)); break;
             case OP_SQRN: {
-                Fr v = slot_load(a.slots, in.a, n, p);
+                Fr v = sf.load(in.a);
                 for (uint32_t i = 0; i < in.b; ++i) v = v.sqr();
-                slot_store(a.slots, in.d, n, p, v);
+                sf.store(in.d, v);
                 break;
             }
-            case OP_LOAD_SCALAR: {
-                const uint8_t* b = a.proofs + (size_t)p * a.proof_len + a.scalar_offsets[in.a];
-                uint8_t tmp[32];
-                for (int i = 0; i < 32; ++i) tmp[i] = b[i];
-                Fr v;
-                if (!Fr::from_bytes(tmp, v)) v = Fr::zero();  // status already set by k_check_scalars
-                slot_store(a.slots, in.d, n, p, v);
-                break;
-            }
-            case OP_LOAD_INST: {
-                const uint8_t* b = a.inst + ((size_t)p * a.ninst + in.a) * 32;
-                uint8_t tmp[32];
-                for (int i = 0; i < 32; ++i) tmp[i] = b[i];
-                Fr v;
-                if (!Fr::from_bytes(tmp, v)) v = Fr::zero();
-                slot_store(a.slots, in.d, n, p, v);
-                break;
-            }
-            case OP_LOAD_CHAL: slot_store(a.slots, in.d, n, p, a.chal[(size_t)in.a * n + p]); break;
-            case OP_LOAD_INSTEVAL: slot_store(a.slots, in.d, n, p, a.insteval[(size_t)in.a * n + p]); break;
-            case OP_LOAD_MULT: slot_store(a.slots, in.d, n, p, a.mult[p]); break;
+            case OP_LOAD_SCALAR: sf.store(in.d, fr_from_le32(a.proofs + (size_t)p * a.proof_len + a.scalar_offsets[in.a])); break;  // status already set by k_check_scalars
+            case OP_LOAD_INST: sf.store(in.d, fr_from_le32(a.inst + ((size_t)p * a.ninst + in.a) * 32)); break;
+            case OP_LOAD_CHAL: sf.store(in.d, a.chal[(size_t)in.a * n + p]); break;
+            case OP_LOAD_INSTEVAL: sf.store(in.d, a.insteval[(size_t)in.a * n + p]); break;
+            case OP_LOAD_MULT: sf.store(in.d, a.mult[p]); break;
             case OP_STORE_MSM: {
                 uint32_t raw[8];
-                slot_load(a.slots, in.a, n, p).to_raw(raw);
+                sf.load(in.a).to_raw(raw);
                 bool bad = a.status[p] != 0;
                 uint32_t* dst = a.msm_scal + ((size_t)p * a.np + in.b) * 8;
                 for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
             }
             case OP_STORE_SHARED: {
-                Fr v = slot_load(a.slots, in.a, n, p);
+                Fr v = sf.load(in.a);
                 if (a.status[p] != 0) v = Fr::zero();
                 a.shared[(size_t)in.b * n + p] = v;
                 break;
             }
             case OP_STORE_LEFT: {
                 uint32_t raw[8];
-                slot_load(a.slots, in.a, n, p).to_raw(raw);
+                sf.load(in.a).to_raw(raw);
                 bool bad = a.status[p] != 0;
                 uint32_t* dst = a.left_scal + ((size_t)p * a.np + in.b) * 8;
                 for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
@@ -475,9 +492,21 @@ int instance_eval_enqueue(hipStream_t s, const InstEvalArgs& a) {
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int frvm_enqueue(hipStream_t s, const FrvmArgs& a) {
+int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     if (!a.n) return 0;
-    hipLaunchKernelGGL(k_frvm, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+    // LDS for the hottest slots: 2304 bytes per slot and wave.  Every wave should still get a CU of its own (a program is a
+    // latency chain, and a second wave on the CU slows both), so the budget follows the number of waves: the whole 160 KB of a
+    // CU while there are at most 256 waves, half of it up to 512, a third beyond.
+    const uint32_t waves = (a.n + 63) / 64;
+    const uint32_t budget = waves <= 256 ? 156 * 1024 : (waves <= 512 ? 78 * 1024 : 52 * 1024);
+    const uint32_t lds_slots = std::min<uint32_t>(n_slots, budget / (H2V_LIMBS * 64 * 4));
+    const size_t lds = (size_t)lds_slots * H2V_LIMBS * 64 * 4;
+    static std::atomic<size_t> granted{0};   // raising the limit is per function and sticky; do it once per size class
+    if (lds > 64 * 1024 && granted.load() < lds) {
+        H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_frvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        granted.store(160 * 1024);
+    }
+    hipLaunchKernelGGL(k_frvm, dim3(waves), dim3(64), lds, s, a, lds_slots);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -62,6 +62,7 @@ enum VmOp : uint32_t {
     OP_LOAD_INSTEVAL = 16, // d <- instance-query evaluation #a of this proof, computed by k_instance_eval (wide instance vectors)
 };
 struct VmInstr { uint32_t op, d, a, b; };
+#define VM_CONST_OPERAND 0x80000000u   // operand a / b of MUL, ADD, SUB: consts[index] instead of a slot
 
 struct TranscriptSrc {  // one byte of the absorbed stream
     enum Kind : uint8_t { CONST = 0, PROOF = 1, PROOF_MASKED = 2, YCOORD = 3, INSTANCE = 4 };

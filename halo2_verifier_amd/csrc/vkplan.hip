@@ -47,7 +47,8 @@ bool read_g1(Reader& r, int fmt, G1A& p, std::string& err) {
         return true;
     }
     const uint8_t* b = r.take(64);
-    bool ok = field_from_mont_bytes(b, p.x) & field_from_mont_bytes(b + 32, p.y);
+    const bool okx = field_from_mont_bytes(b, p.x), oky = field_from_mont_bytes(b + 32, p.y);
+    bool ok = okx && oky;
     if (fmt == H2V_SERDE_RAW_BYTES && (!ok || !p.on_curve())) { err = "invalid uncompressed point"; return false; }
     return true;
 }
@@ -215,42 +216,73 @@ struct Builder {
         vals[0] = run;
     }
 
-    // liveness-based slot assignment; emits the final instruction stream
+    // Emits the final instruction stream: emission order, then liveness-based slot assignment.
+    //  * constants are OPERANDS of MUL / ADD / SUB (VM_CONST_OPERAND | index): no instruction, no slot; a constant that feeds
+    //    anything else is materialised by an OP_CONST right before that use;
+    //  * LOAD_* nodes are emitted at their first use, not where the builder created them (it creates all of a proof's
+    //    evaluations up front: twenty values that would otherwise sit in slots for most of the program).
+    // Fewer live values = fewer slots = all of them in LDS (k_frvm).
+    static bool is_load(uint32_t op) { return op == OP_LOAD_SCALAR || op == OP_LOAD_INST || op == OP_LOAD_CHAL || op == OP_LOAD_MULT || op == OP_LOAD_INSTEVAL; }
+    static bool takes_const_operands(uint32_t op) { return op == OP_MUL || op == OP_ADD || op == OP_SUB; }
     void emit(std::vector<VmInstr>& code, uint32_t& n_slots) const {
-        size_t n = nodes.size();
-        std::vector<size_t> last_use(n, 0);
+        const size_t n = nodes.size();
+        auto n_operands = [&](const Node& nd) -> int {
+            switch (nd.op) {
+                case OP_MUL: case OP_ADD: case OP_SUB: return 2;
+                case OP_NEG: case OP_INV: case OP_POW: case OP_SQRN: case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: return 1;
+                default: return 0;
+            }
+        };
+        std::vector<Val> order;
+        std::vector<char> emitted(n, 0);
         for (size_t i = 0; i < n; ++i) {
             const Node& nd = nodes[i];
-            auto use = [&](Val v) { last_use[v] = std::max(last_use[v], i); };
-            switch (nd.op) {
-                case OP_MUL: case OP_ADD: case OP_SUB: use(nd.a); use(nd.b); break;
-                case OP_NEG: case OP_INV: case OP_POW: case OP_SQRN: case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: use(nd.a); break;
-                default: break;
+            if (nd.op == OP_CONST || is_load(nd.op)) continue;   // on demand
+            const int k = n_operands(nd);
+            for (int j = 0; j < k; ++j) {
+                const Val v = j == 0 ? nd.a : nd.b;
+                if (emitted[v]) continue;
+                const bool c = nodes[v].op == OP_CONST;
+                if (is_load(nodes[v].op) || (c && !takes_const_operands(nd.op))) { order.push_back(v); emitted[v] = 1; }
             }
+            order.push_back((Val)i); emitted[i] = 1;
+        }
+        const size_t m = order.size();
+        std::vector<size_t> pos(n, (size_t)-1), last_use(n, 0);
+        for (size_t q = 0; q < m; ++q) pos[order[q]] = q;
+        for (size_t q = 0; q < m; ++q) {
+            const Node& nd = nodes[order[q]];
+            const int k = n_operands(nd);
+            for (int j = 0; j < k; ++j) { const Val v = j == 0 ? nd.a : nd.b; if (emitted[v]) last_use[v] = std::max(last_use[v], q); }
         }
         std::vector<uint32_t> slot(n, 0), free_list;
-        std::vector<std::vector<Val>> dying(n);
-        for (size_t v = 0; v < n; ++v) if (nodes[v].has_result) dying[std::max(last_use[v], v)].push_back((Val)v);
+        std::vector<std::vector<Val>> dying(m);
+        for (size_t q = 0; q < m; ++q) if (nodes[order[q]].has_result) dying[std::max(last_use[order[q]], q)].push_back(order[q]);
         uint32_t next = 0;
-        for (size_t i = 0; i < n; ++i) {
+        auto operand = [&](uint32_t consumer_op, Val v) -> uint32_t {
+            if (nodes[v].op == OP_CONST && takes_const_operands(consumer_op)) return VM_CONST_OPERAND | nodes[v].imm;
+            return slot[v];
+        };
+        for (size_t q = 0; q < m; ++q) {
+            const Val i = order[q];
             const Node& nd = nodes[i];
             VmInstr in{nd.op, 0, 0, 0};
             switch (nd.op) {
-                case OP_MUL: case OP_ADD: case OP_SUB: in.a = slot[nd.a]; in.b = slot[nd.b]; break;
+                case OP_MUL: case OP_ADD: case OP_SUB: in.a = operand(nd.op, nd.a); in.b = operand(nd.op, nd.b); break;
                 case OP_NEG: case OP_INV: in.a = slot[nd.a]; break;
                 case OP_POW: case OP_SQRN: in.a = slot[nd.a]; in.b = nd.imm; break;
                 case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: in.a = slot[nd.a]; in.b = nd.imm; break;
                 default: in.a = nd.imm; break;  // CONST / LOAD_*
             }
             if (nd.has_result) {
-                // the destination may not alias a source that is read in the same instruction after being
-                // written; the interpreter reads both operands before it writes, so reuse is safe even then
-                uint32_t s;
-                if (!free_list.empty()) { s = free_list.back(); free_list.pop_back(); } else s = next++;
-                slot[i] = s; in.d = s;
+                // the interpreter reads both operands before it writes, so the destination may reuse the slot of an operand
+                // that dies here; lowest free slot first: the low numbers are the ones kept in LDS
+                uint32_t sl;
+                if (!free_list.empty()) { auto it = std::min_element(free_list.begin(), free_list.end()); sl = *it; free_list.erase(it); } else sl = next++;
+                slot[i] = sl; in.d = sl;
             }
             code.push_back(in);
-            for (Val v : dying[i]) free_list.push_back(slot[v]);
+            for (Val v : dying[q]) free_list.push_back(slot[v]);
         }
         n_slots = next ? next : 1;
     }

@@ -45,6 +45,8 @@ template <class F> static int run() {
         else if (o == "neg") print(x.neg());
         else if (o == "dbl") print(x.dbl());
         else if (o == "inv") print(x.inv());
+        else if (o == "invf") print(x.inv_fermat());          // the fixed-exponent chain, kept as the cross-check of inv()
+        else if (o == "invl") print((x + y - y).inv());       // a lazily reduced operand (representative in [p, 2p) half of the time)
         else if (o == "dot2") print(F::dot2_inl(x, y, z, w));
         else if (o == "chain") {            // (((x*y - x) + y)^2 - y) * x : lazily reduced intermediates feed every kind of operation
             F t = x * y - x; t = t + y; t = t.sqr() - y; print(t * x);

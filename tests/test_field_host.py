@@ -55,6 +55,15 @@ def test_field_operations_match_big_integers(exe, field):
     for _ in range(4000):
         a, b, c, d = (rnd.randrange(p) for _ in range(4))
         lines.append(f"wide {h(a)} {h(b)} {h(c)} {h(d)}"); want.append(h((9 * a - b - 9 * c + d + a + b) % p))
+    # inversion: safegcd divsteps (inv) against Python's pow and against the Fermat chain (invf), incl. lazily reduced operands,
+    # values with long runs of zero / one bits and the small values that make g vanish early
+    special = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 253, (1 << 253) - 1, (1 << 128), (1 << 128) - 1, (1 << 30) - 1, 1 << 30,
+               (1 << 60) + 1, p - (1 << 200), 0x5555555555555555555555555555555555555555555555555555555555555555 % p]
+    for a in special + [rnd.randrange(p) for _ in range(600)]:
+        lines.append(f"inv {h(a)}"); want.append(h(pow(a, -1, p) if a else 0))
+        lines.append(f"invl {h(a)} {h(rnd.randrange(p))}"); want.append(h(pow(a, -1, p) if a else 0))
+    for a in special + [rnd.randrange(p) for _ in range(40)]:
+        lines.append(f"invf {h(a)}"); want.append(h(pow(a, -1, p) if a else 0))
     # halo2curves' in-memory Montgomery words (R = 2^256) -> this representation
     for _ in range(20):
         a = rnd.randrange(p)
