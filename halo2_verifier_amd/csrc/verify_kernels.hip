@@ -4,7 +4,7 @@
 //   k_decompress      one lane per (proof, point)   G1Affine::from_bytes               transcript/mod.rs:158-166
 //   k_check_scalars   one lane per (proof, scalar)  Fr::from_repr canonicity           transcript/mod.rs:168-176
 //   k_stream_build    one lane per (proof, 8-byte word of the absorbed stream)         transcript/mod.rs:216-231
-//   k_transcript      one lane per proof            Blake2b-512 + challenges           transcript/mod.rs:124-133,209-214,500-514
+//   k_transcript      four lanes per proof          Blake2b-512 + challenges           transcript/mod.rs:124-133,209-214,500-514
 //   k_multipliers     one workgroup                 suffix products of the batch draws kzg/strategy.rs:129, msm.rs:173-176
 //   k_instance_eval   one workgroup per proof       Lagrange sum over a wide instance column   lib.rs:173-218, poly/domain.rs:187-212
 //   k_frvm            one lane per proof            the compiled Fr program            lib.rs:173-346, shplonk.rs:202-264
@@ -88,66 +88,93 @@ __constant__ uint8_t BLAKE_SIGMA[12][16] = {
     {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
     {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
 
-__device__ __noinline__ void blake2b_compress(unsigned long long h[8], const unsigned long long m[16], unsigned long long t, bool last) {
-    unsigned long long v[16];
-    for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = BLAKE_IV[i]; }
-    v[12] ^= t;  // t1 = 0: streams are far below 2^64 bytes
-    if (last) v[14] = ~v[14];
-#define H2V_G(a, b, c, d, x, y)                                     \
-    v[a] = v[a] + v[b] + (x); v[d] = rotr64(v[d] ^ v[a], 32);       \
-    v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 24);       \
-    v[a] = v[a] + v[b] + (y); v[d] = rotr64(v[d] ^ v[a], 16);       \
-    v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 63);
-#pragma unroll
-    for (int r = 0; r < 12; ++r) {
-        H2V_G(0, 4, 8, 12, m[BLAKE_SIGMA[r][0]], m[BLAKE_SIGMA[r][1]]);
-        H2V_G(1, 5, 9, 13, m[BLAKE_SIGMA[r][2]], m[BLAKE_SIGMA[r][3]]);
-        H2V_G(2, 6, 10, 14, m[BLAKE_SIGMA[r][4]], m[BLAKE_SIGMA[r][5]]);
-        H2V_G(3, 7, 11, 15, m[BLAKE_SIGMA[r][6]], m[BLAKE_SIGMA[r][7]]);
-        H2V_G(0, 5, 10, 15, m[BLAKE_SIGMA[r][8]], m[BLAKE_SIGMA[r][9]]);
-        H2V_G(1, 6, 11, 12, m[BLAKE_SIGMA[r][10]], m[BLAKE_SIGMA[r][11]]);
-        H2V_G(2, 7, 8, 13, m[BLAKE_SIGMA[r][12]], m[BLAKE_SIGMA[r][13]]);
-        H2V_G(3, 4, 9, 14, m[BLAKE_SIGMA[r][14]], m[BLAKE_SIGMA[r][15]]);
-    }
-#undef H2V_G
-    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+// ---- BLAKE2b across a quad of lanes.  The compression function works on a 4 x 4 matrix of 64-bit words: a column step (four
+// independent G functions) and a diagonal step (four more).  Lane r of a quad holds column r (v[r], v[4+r], v[8+r], v[12+r]);
+// the diagonal step is the column step after rotating rows 1..3 by 1..3 lanes (DPP quad permutes, no LDS).  One proof per quad:
+// the ~21 dependent compressions of a proof's transcript take a quarter of the instructions per lane — the transcript is a
+// latency chain (16 waves per 1024 proofs), so that is a quarter of its time.
+__device__ __forceinline__ unsigned long long quad_rot64(unsigned long long x, const int ctrl_sel) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    // ctrl_sel: 1 -> lane r reads lane (r + 1) & 3, 2 -> (r + 2) & 3, 3 -> (r + 3) & 3
+    if (ctrl_sel == 1) { lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x39, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x39, 0xf, 0xf, true); }
+    else if (ctrl_sel == 2) { lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x4e, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x4e, 0xf, 0xf, true); }
+    else { lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x93, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x93, 0xf, 0xf, true); }
+    return ((unsigned long long)hi << 32) | lo;
 }
+#define H2V_G4(a, b, c, d, x, y)                     \
+    a = a + b + (x); d = rotr64(d ^ a, 32);          \
+    c = c + d;       b = rotr64(b ^ c, 24);          \
+    a = a + b + (y); d = rotr64(d ^ a, 16);          \
+    c = c + d;       b = rotr64(b ^ c, 63);
+// h0 = h[r], h1 = h[4 + r]; msg = this proof's 16 message words in LDS; sig[rd] packs the lane's four message indices of round rd
+__device__ __forceinline__ void blake2b_compress_quad(unsigned long long& h0, unsigned long long& h1, const unsigned long long* msg, const uint32_t* sig,
+                                                       unsigned long long t, bool last, uint32_t r) {
+    unsigned long long a = h0, b = h1, c = BLAKE_IV[r], d = BLAKE_IV[4 + r];
+    if (r == 0) d ^= t;           // v12 ^= t0 (t1 = 0: streams are far below 2^64 bytes)
+    if (last && r == 2) d = ~d;   // v14
+#pragma unroll
+    for (int rd = 0; rd < 12; ++rd) {
+        const uint32_t s4 = sig[rd];
+        H2V_G4(a, b, c, d, msg[s4 & 15u], msg[(s4 >> 4) & 15u]);
+        b = quad_rot64(b, 1); c = quad_rot64(c, 2); d = quad_rot64(d, 3);
+        H2V_G4(a, b, c, d, msg[(s4 >> 8) & 15u], msg[(s4 >> 12) & 15u]);
+        b = quad_rot64(b, 3); c = quad_rot64(c, 2); d = quad_rot64(d, 1);
+    }
+    h0 ^= a ^ c; h1 ^= b ^ d;
+}
+#undef H2V_G4
 
+#define TR4_MSG_STRIDE 17   // 16 message words + 1: the sixteen proofs of a wave hit sixteen different LDS banks
 // squeeze_at[q] = absorbed length at which challenge q is produced: digest(stream[0..L)) with the state
-// cloned (transcript/mod.rs:209-214), 64 bytes -> Fr::from_uniform_bytes (:500-514).
+// cloned (transcript/mod.rs:209-214), 64 bytes -> Fr::from_uniform_bytes (:500-514).  16 proofs per wave.
 __global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __restrict__ words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
                                                    uint32_t n, Fr* __restrict__ chal) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    unsigned long long h[8];
-    {   // parameter block: digest 64, no key, fanout = depth = 1, personal "Halo2-Transcript" (transcript/mod.rs:126-129)
-        const unsigned long long pers0 = 0x72542d326f6c6148ULL, pers1 = 0x7470697263736e61ULL;  // "Halo2-Tr" "anscript" little endian
-        for (int i = 0; i < 8; ++i) h[i] = BLAKE_IV[i];
-        h[0] ^= 0x01010040ULL; h[6] ^= pers0; h[7] ^= pers1;
-    }
+    extern __shared__ unsigned long long tr_lds[];   // [16][TR4_MSG_STRIDE] message block, then [16][n_squeeze][8] digests
+    const uint32_t tid = threadIdx.x, r = tid & 3u, pq = tid >> 2;
+    const uint32_t p_raw = blockIdx.x * 16 + pq, p = p_raw < n ? p_raw : n - 1;   // lanes beyond n shadow the last proof (uniform control flow)
+    unsigned long long* msg = tr_lds + pq * TR4_MSG_STRIDE;
+    unsigned long long* dig = tr_lds + 16 * TR4_MSG_STRIDE + (size_t)pq * n_squeeze * 8;
+    uint32_t sig[12];
+#pragma unroll
+    for (int rd = 0; rd < 12; ++rd)
+        sig[rd] = (uint32_t)BLAKE_SIGMA[rd][2 * r] | ((uint32_t)BLAKE_SIGMA[rd][2 * r + 1] << 4) | ((uint32_t)BLAKE_SIGMA[rd][8 + 2 * r] << 8) | ((uint32_t)BLAKE_SIGMA[rd][9 + 2 * r] << 12);
+    // parameter block: digest 64, no key, fanout = depth = 1, personal "Halo2-Transcript" (transcript/mod.rs:126-129)
+    const unsigned long long pers0 = 0x72542d326f6c6148ULL, pers1 = 0x7470697263736e61ULL;  // "Halo2-Tr" "anscript" little endian
+    unsigned long long h0 = BLAKE_IV[r] ^ (r == 0 ? 0x01010040ULL : 0ULL), h1 = BLAKE_IV[4 + r] ^ (r == 2 ? pers0 : (r == 3 ? pers1 : 0ULL));
     uint32_t blk = 0;
     for (uint32_t q = 0; q < n_squeeze; ++q) {
-        uint32_t len = squeeze_at[q];  // >= 1
-        uint32_t last_blk = (len - 1) / 128;
-        unsigned long long m[16];
+        const uint32_t len = squeeze_at[q];  // >= 1
+        const uint32_t last_blk = (len - 1) / 128;
         for (; blk < last_blk; ++blk) {
-            for (int j = 0; j < 16; ++j) m[j] = words[((size_t)blk * 16 + j) * n + p];
-            blake2b_compress(h, m, (unsigned long long)(blk + 1) * 128, false);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) msg[4 * r + j] = words[((size_t)blk * 16 + 4 * r + j) * n + p];
+            __syncthreads();
+            blake2b_compress_quad(h0, h1, msg, sig, (unsigned long long)(blk + 1) * 128, false, r);
         }
-        uint32_t rem = len - last_blk * 128;  // 1..128 bytes of the final block
-        for (int j = 0; j < 16; ++j) {
-            unsigned long long w = words[((size_t)last_blk * 16 + j) * n + p];
-            uint32_t lo = 8 * j;
+        const uint32_t rem = len - last_blk * 128;  // 1..128 bytes of the final block
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            unsigned long long w = words[((size_t)last_blk * 16 + 4 * r + j) * n + p];
+            const uint32_t lo = 8 * (4 * r + j);
             if (lo >= rem) w = 0;
             else if (lo + 8 > rem) w &= (1ULL << (8 * (rem - lo))) - 1;
-            m[j] = w;
+            msg[4 * r + j] = w;
         }
-        unsigned long long hc[8];
-        for (int i = 0; i < 8; ++i) hc[i] = h[i];
-        blake2b_compress(hc, m, len, true);
+        __syncthreads();
+        unsigned long long c0 = h0, c1 = h1;   // the clone
+        blake2b_compress_quad(c0, c1, msg, sig, len, true, r);
+        dig[q * 8 + r] = c0; dig[q * 8 + 4 + r] = c1;
+    }
+    __syncthreads();
+    // 64 digest bytes -> Fr; the quad's lanes share the challenges
+    for (uint32_t q = r; q < n_squeeze; q += 4) {
         uint32_t w32[16];
-        for (int i = 0; i < 8; ++i) { w32[2 * i] = (uint32_t)hc[i]; w32[2 * i + 1] = (uint32_t)(hc[i] >> 32); }
-        chal[(size_t)q * n + p] = Fr::from_uniform_words(w32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const unsigned long long v = dig[q * 8 + i]; w32[2 * i] = (uint32_t)v; w32[2 * i + 1] = (uint32_t)(v >> 32); }
+        const Fr c = Fr::from_uniform_words(w32);
+        if (p_raw < n) chal[(size_t)q * n + p] = c;
     }
 }
 
@@ -465,7 +492,12 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
     if (pl.opts.transcript == H2V_TRANSCRIPT_KECCAK256)
         hipLaunchKernelGGL(k_transcript_keccak, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
     else
-        hipLaunchKernelGGL(k_transcript, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
+    {
+        const uint32_t nsq = (uint32_t)pl.squeeze_at.size();
+        const size_t lds = ((size_t)16 * TR4_MSG_STRIDE + (size_t)16 * nsq * 8) * 8;
+        if (lds > 60 * 1024) { set_last_error("transcript: too many challenges for one workgroup's LDS"); return H2V_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(k_transcript, dim3((n + 15) / 16), dim3(64), lds, s, g.words, g.pd->squeeze_at, nsq, n, g.chal);
+    }
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
