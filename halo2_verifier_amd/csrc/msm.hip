@@ -16,7 +16,7 @@
 //                   exclusive prefix sum of the histogram in three small launches (1024 bins per workgroup)
 //   3. msm_scatter  same tiles: LDS histogram again, one global atomic per (tile, bucket) reserves the tile's span of
 //                   the bucket's list, LDS atomics hand out positions inside it
-//   4. msm_accumulate  the sorted list is cut into CHUNKS OF EQUAL LENGTH (32 entries), one lane per chunk, whatever the
+//   4. msm_accumulate  the sorted list is cut into CHUNKS OF EQUAL LENGTH (16..64 entries, msm_chunk_len), one lane per chunk, whatever the
 //                   bucket boundaries: every lane does the same number of mixed additions, so a wave is not held up by its
 //                   fullest bucket (with ~13 entries per bucket on average a lane-per-bucket mapping idles ~45 % of the
 //                   lanes) and no bucket is ever too big for a lane (the top window of a 254-bit scalar is only a few bits
@@ -43,7 +43,19 @@
 
 namespace h2v {
 
-#define MSM_CHUNK 32u            // list entries per lane of msm_accumulate
+// List entries per lane of msm_accumulate ("chunk"), chosen ON THE DEVICE from the number of entries E the sort produced: the
+// kernel holds 2 waves per SIMD (131072 lanes per round), and with a fixed chunk of 32 a 20-step launch (6.4 M entries) needed
+// 1.5 rounds — the second one half empty, i.e. the time of 64 additions per SIMD slot for 49 additions' worth of work.  The chunk
+// is the smallest length that fits E into a whole number of rounds (k rounds of at most 64 entries per lane), at least 16.
+#define MSM_CHUNK_MIN 16u
+#define MSM_CHUNK_MAX 64u
+#define MSM_ACC_LANES_PER_ROUND 131072u
+__host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E) {
+    if (E <= MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MIN) return MSM_CHUNK_MIN;
+    const uint32_t k = (uint32_t)(((uint64_t)E + (uint64_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX - 1) / ((uint64_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX));
+    const uint32_t c = (uint32_t)(((uint64_t)E + (uint64_t)k * MSM_ACC_LANES_PER_ROUND - 1) / ((uint64_t)k * MSM_ACC_LANES_PER_ROUND));
+    return c < MSM_CHUNK_MIN ? MSM_CHUNK_MIN : c;
+}
 #define MSM_FIXUP_SERIAL 64u     // a bucket spread over more chunks than this is summed by a workgroup
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
@@ -109,7 +121,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
-    H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK + 1) * 2 * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
     for (int i = 0; i < 2; ++i) if (!ev_acc[i]) H2V_HIP_CHECK(hipEventCreate(&ev_acc[i]));
     return 0;
 }
@@ -362,7 +374,8 @@ __device__ __forceinline__ G1JSlot* msm_piece_dst(G1JSlot* __restrict__ bucket_p
 // complete (slow, call-based) group law for the rare chunk in which a point meets itself or its negative
 __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                             const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E) {
-    const uint32_t chunk_lo = lane * MSM_CHUNK, chunk_hi = min(chunk_lo + MSM_CHUNK, E);
+    const uint32_t CH = msm_chunk_len(E);
+    const uint32_t chunk_lo = lane * CH, chunk_hi = min(chunk_lo + CH, E);
     uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
     uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
     MsmProblem q = prs[b / nbq];
@@ -388,12 +401,13 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
     // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
     // each) instead of all of them (15 MB per 16-step launch): the gathers hit in L2 instead of going out to the fabric.
-    const uint32_t blocks = ((E + MSM_CHUNK - 1) / MSM_CHUNK + 63) / 64, per_xcd = (blocks + 7) / 8;
+    const uint32_t CH = msm_chunk_len(E);
+    const uint32_t blocks = ((E + CH - 1) / CH + 63) / 64, per_xcd = (blocks + 7) / 8;
     if (blockIdx.x / 8 >= per_xcd) return;
     const uint32_t lane = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * 64 + threadIdx.x;
-    const uint32_t chunk_lo = lane * MSM_CHUNK;
+    const uint32_t chunk_lo = lane * CH;
     if (chunk_lo >= E) return;
-    const uint32_t chunk_hi = min(chunk_lo + MSM_CHUNK, E);
+    const uint32_t chunk_hi = min(chunk_lo + CH, E);
     uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
     uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
     uint32_t qi = b / nbq;
@@ -429,12 +443,12 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
-__device__ __forceinline__ const G1JSlot* msm_piece_src(const G1JSlot* __restrict__ partial, uint32_t i, uint32_t i0, uint32_t off) {
-    return partial + 2 * (size_t)i + ((i == i0 && off > i0 * MSM_CHUNK) ? 1 : 0);
+__device__ __forceinline__ const G1JSlot* msm_piece_src(const G1JSlot* __restrict__ partial, uint32_t i, uint32_t i0, uint32_t off, uint32_t CH) {
+    return partial + 2 * (size_t)i + ((i == i0 && off > i0 * CH) ? 1 : 0);
 }
-__device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial, uint32_t i0, uint32_t i1, uint32_t off, G1JSlot* __restrict__ out) {
-    G1J acc = msm_piece_src(partial, i0, i0, off)->p;
-    for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, msm_piece_src(partial, i, i0, off)->p);
+__device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial, uint32_t i0, uint32_t i1, uint32_t off, uint32_t CH, G1JSlot* __restrict__ out) {
+    G1J acc = msm_piece_src(partial, i0, i0, off, CH)->p;
+    for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, msm_piece_src(partial, i, i0, off, CH)->p);
     *out = acc;
 }
 // After the scatter `cursor` is free and becomes two work lists: buckets that straddle chunks, from the front (their number
@@ -446,7 +460,8 @@ __global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__
     if (b >= nb) return;
     const uint32_t cnt = counts[b], off = offsets[b];
     if (cnt == 0) { bucket_pts[b] = G1J::identity(); return; }
-    const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
+    const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+    const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
     if (i0 == i1) return;  // written whole by its chunk
     if (i1 - i0 >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&counts[nb], 1u)] = b;
     else lists[atomicAdd(&counts[nb + 2], 1u)] = b;
@@ -457,12 +472,13 @@ __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ cou
     if (k >= counts[nb + 2]) return;
     const uint32_t b = lists[k];
     const uint32_t cnt = counts[b], off = offsets[b];
-    const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
+    const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+    const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
     // in-register additions; pieces of one bucket can coincide or cancel (the same point in two chunks): complete formulas then
-    G1J acc = msm_piece_src(partial, i0, i0, off)->p;
+    G1J acc = msm_piece_src(partial, i0, i0, off, CH)->p;
     bool ok = true;
-    for (uint32_t i = i0 + 1; i <= i1 && ok; ++i) ok = g1_add_fast(acc, msm_piece_src(partial, i, i0, off)->p);
-    if (!ok) { msm_fixup_slow(partial, i0, i1, off, bucket_pts + b); return; }
+    for (uint32_t i = i0 + 1; i <= i1 && ok; ++i) ok = g1_add_fast(acc, msm_piece_src(partial, i, i0, off, CH)->p);
+    if (!ok) { msm_fixup_slow(partial, i0, i1, off, CH, bucket_pts + b); return; }
     bucket_pts[b] = acc;
 }
 __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
@@ -474,9 +490,10 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const uint32_t b = heavy[nb - 1 - h];
         const uint32_t cnt = counts[b], off = offsets[b];
-        const uint32_t i0 = off / MSM_CHUNK, i1 = (off + cnt - 1) / MSM_CHUNK;
+        const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+        const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
         G1J acc = G1J::identity();
-        for (uint32_t i = i0 + t; i <= i1; i += MSM_HEAVY_THREADS) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off));
+        for (uint32_t i = i0 + t; i <= i1; i += MSM_HEAVY_THREADS) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off, CH));
         red[t] = acc;
         __syncthreads();
         for (uint32_t d = MSM_HEAVY_THREADS / 2; d > 0; d >>= 1) {
@@ -602,7 +619,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, count, tiles, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
     // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers its upper bound
     const size_t max_entries = total * 2 * p.windows;
-    const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK - 1) / MSM_CHUNK);
+    const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN);   // surplus workgroups return at once
     if (ws.profile) hipEventRecord(ws.ev_acc[0], s);
     hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
     if (ws.profile) { hipEventRecord(ws.ev_acc[1], s); ws.profile_recorded = true; }
