@@ -78,7 +78,7 @@ struct h2v_batch {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     hipStream_t aux = nullptr;        // the accumulators' affine conversion runs here, beside the pairing (both only read them)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
     size_t max_proofs = 0, max_inst = 0;
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
     uint32_t n = 0, n_tail = 0;

@@ -125,16 +125,22 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     int ev = 0;
     auto mark = [&]() { if (b->profiling) hipEventRecord(b->ev[ev], s); ++ev; };
     mark();
+    H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this launch (uploads) is visible to the auxiliary stream
     StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->ycanon, b->status, b->words, b->stream_words, b->chal};
     // stage 1: point decompression + canonicity checks; stage 2: absorbed stream, Blake2b challenges, batch multipliers
     if ((rc = decompress_stage_enqueue(s, g))) return rc;
     mark();
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
+    // the batch multipliers depend only on the uploaded draws: they run on the auxiliary stream beside decompression and transcript
     if (n) {
+        H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork0, 0));
+        hipStream_t sm = b->aux;
         // multipliers: suffix products of the uploaded draws — or, for a batch that is a non-contiguous subset of a larger
         // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
-        if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(s, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
-        else if ((rc = multipliers_enqueue(s, b->tail, b->n_tail, n, G, b->mult))) return rc;
+        if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(sm, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
+        else if ((rc = multipliers_enqueue(sm, b->tail, b->n_tail, n, G, b->mult))) return rc;
+        H2V_HIP_CHECK(hipEventRecord(b->ev_join0, sm));
+        H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join0, 0));   // joined before the Fr program reads them
     }
     mark();
     if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
@@ -358,6 +364,7 @@ int h2v_batch_create(h2v_ctx* ctx, size_t max_proofs, size_t max_instance_values
     }
     for (int i = 0; i < 8; ++i) hipEventCreate(&b->ev[i]);
     hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_fork0, hipEventDisableTiming); hipEventCreateWithFlags(&b->ev_join0, hipEventDisableTiming);
     *out = b;
     return 0;
 }
@@ -374,6 +381,8 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (b->aux) { hipStreamSynchronize(b->aux); hipStreamDestroy(b->aux); }
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
     if (b->ev_join) hipEventDestroy(b->ev_join);
+    if (b->ev_fork0) hipEventDestroy(b->ev_fork0);
+    if (b->ev_join0) hipEventDestroy(b->ev_join0);
     if (b->stream && b->owns_stream) hipStreamDestroy(b->stream);
     delete b;
 }

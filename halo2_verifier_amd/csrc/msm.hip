@@ -28,7 +28,7 @@
 //                   go to msm_fixup_heavy, one workgroup each)
 //   5. msm_window   one wave (four for more than 2048 buckets) per (problem, window): sum_b (b+1) * bucket[b] by per-lane
 //                   running sums over a slice of buckets, then a cross-lane butterfly (wave shuffles; LDS tree for four waves)
-//   6. msm_final    one lane per problem: Horner over windows (c doublings + one add per window)
+//   6. msm_final    four lanes per problem: Horner over windows (c doublings + one add per window), every doubling split over the quad
 //
 // Steps 1-3 are a hand-written counting sort (no atomics on points, no library sort); the only
 // atomics are 32-bit counters.  The order of additions inside a bucket depends on atomic
@@ -565,17 +565,55 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
     if (t == 0) window_sums[(size_t)q * p.windows + w] = red[0];
 }
 
+// ---- msm_final: Horner over the windows — c doublings and one addition per window, ~130 dependent group operations, nothing
+// to parallelise ACROSS operations.  Four lanes (a quad) work on one problem and split the inside of a doubling instead:
+//   level 1   lane 0: A = X^2     lane 1: B = Y^2         lane 2: YZ = Y Z
+//   level 2   lane 0: C = B^2     lane 1: (X + B)^2       lane 2: F = (3A)^2
+//   level 3   every lane: E (D - X3)
+// three products deep instead of seven, values exchanged by DPP quad broadcasts (no LDS).  X, Y, Z are replicated in the four
+// lanes; the one addition per window is done redundantly by all of them (nothing to exchange).
+template <int S> __device__ __forceinline__ Fq quad_bcast(const Fq& v) {
+    Fq r;
+#pragma unroll
+    for (int l = 0; l < H2V_LIMBS; ++l) r.v[l] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.v[l], S * 0x55, 0xf, 0xf, true);   // quad_perm [S,S,S,S]
+    return r;
+}
+__device__ __forceinline__ Fq fq_sel(bool c, const Fq& a, const Fq& b) {
+    Fq r;
+#pragma unroll
+    for (int l = 0; l < H2V_LIMBS; ++l) r.v[l] = c ? a.v[l] : b.v[l];
+    return r;
+}
+__device__ __forceinline__ void g1_dbl_quad(G1J& p, uint32_t r) {
+    // dbl-2009-l for a = 0.  The identity (Z = 0) stays the identity: Z3 = 2 Y Z.
+    const Fq p1 = Fq::mul_inl(fq_sel(r == 0, p.X, p.Y), fq_sel(r == 0, p.X, fq_sel(r == 1, p.Y, p.Z)));
+    const Fq A = quad_bcast<0>(p1), B = quad_bcast<1>(p1), YZ = quad_bcast<2>(p1);
+    // operands of level 2 by uniform code: lane 0: 0 + B, lane 1: X + B, lane 2: A + A, then lane 2 adds A once more
+    const Fq u = fq_sel(r == 1, p.X, fq_sel(r == 2, A, Fq::zero())) + fq_sel(r == 2, A, B);
+    const Fq w = u + fq_sel(r == 2, A, Fq::zero());
+    const Fq p2 = w.sqr_inl();
+    const Fq C = quad_bcast<0>(p2), S = quad_bcast<1>(p2), F = quad_bcast<2>(p2), E = quad_bcast<2>(w);
+    const Fq D = (S - A - C).dbl();
+    const Fq X3 = F - D.dbl();
+    p.Y = Fq::mul_inl(E, D - X3) - C.dbl().dbl().dbl();
+    p.X = X3;
+    p.Z = YZ.dbl();
+}
 __global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p) {
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= count) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3u;
+    if (q >= count) return;   // whole quads
     G1J acc = G1J::identity();
     if (prs[q].n) {
+        G1J next = window_sums[(size_t)q * p.windows + p.windows - 1];
         for (int w = (int)p.windows - 1; w >= 0; --w) {
-            for (uint32_t i = 0; i < p.c; ++i) acc = g1_dbl(acc);
-            acc = g1_add(acc, window_sums[(size_t)q * p.windows + w]);
+            const G1J cur = next;
+            if (w > 0) next = window_sums[(size_t)q * p.windows + w - 1];   // in flight during the doublings
+#pragma unroll 1
+            for (uint32_t i = 0; i < p.c; ++i) g1_dbl_quad(acc, r);
+            acc = g1_add_inl(acc, cur);
         }
     }
-    *prs[q].out = acc;
+    if (r == 0) *prs[q].out = acc;
 }
 
 // descriptors travel as kernel arguments, a chunk at a time: no host staging buffer whose lifetime the caller would have to manage
@@ -597,7 +635,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
         hipLaunchKernelGGL(msm_set_problems, dim3(1), dim3(64), 0, s, ch, k, ws.problems + q0);
     }
     if (nmax == 0) {
-        hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, MsmPlan{0, 2, 0, 3});
+        hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, MsmPlan{0, 2, 0, 3});
         H2V_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -632,7 +670,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
         hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(T), win_lds, s, ws.bucket_pts, ws.window_sums, p);
     }
-    hipLaunchKernelGGL(msm_final, dim3((count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
+    hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
