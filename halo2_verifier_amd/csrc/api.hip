@@ -32,13 +32,14 @@ int h2v_ctx_create_ex(const uint8_t* params, size_t params_len, int params_forma
     if (options && (options->multiopen < 0 || options->multiopen > 1 || options->transcript < 0 || options->transcript > 1)) {
         set_last_error("h2v_ctx_create_ex: unknown multiopen / transcript option"); return H2V_ERR_BAD_ARGUMENT;
     }
+    if (options && (options->circuit_instances < 0 || options->circuit_instances > 64)) { set_last_error("h2v_ctx_create_ex: circuit_instances must be in 0..64 (0 = 1)"); return H2V_ERR_BAD_ARGUMENT; }
     int ndev = h2v_device_count();
     if (device < 0 || device >= ndev) { set_last_error("h2v_ctx_create: no such HIP device (the library has no CPU path)"); return H2V_ERR_DEVICE; }
     h2v_ctx* ctx = new h2v_ctx();
     std::string err;
     if (!params_from_bytes(params, params_len, params_format, ctx->params, err)) { set_last_error("ParamsKZG: " + err); delete ctx; return H2V_ERR_FORMAT; }
     ctx->device = device;
-    if (options) { ctx->multiopen = options->multiopen; ctx->transcript = options->transcript; }
+    if (options) { ctx->multiopen = options->multiopen; ctx->transcript = options->transcript; ctx->circuit_instances = options->circuit_instances > 0 ? options->circuit_instances : 1; }
     if (hipSetDevice(device) != hipSuccess) { set_last_error("hipSetDevice failed"); delete ctx; return H2V_ERR_DEVICE; }
     int rc = ctx->pairing.upload(ctx->params);
     if (rc) { delete ctx; return rc; }

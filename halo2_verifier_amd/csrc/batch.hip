@@ -77,7 +77,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     if (n > b->max_proofs) { set_last_error("h2v_batch_upload: n exceeds the batch capacity"); return H2V_ERR_BAD_ARGUMENT; }
     h2v_ctx* ctx = b->ctx;
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
-    if (ncols != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }  // lib.rs:51-55
+    if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }  // lib.rs:51-55
     std::vector<size_t> lens(col_lens, col_lens + ncols);
     PlanDevice* pd = nullptr;
     int rc = ctx_get_plan(ctx, lens, &pd);
@@ -279,7 +279,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
                  uint8_t* out_right, h2v_batch** keep) {
     if (!ctx || (n && (!proofs || !proof_lens)) || (ncols && !col_lens)) { set_last_error("null argument"); return H2V_ERR_BAD_ARGUMENT; }
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
-    if (ncols != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
+    if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
     std::lock_guard<std::mutex> lock(ctx->mu);   // one one-shot call per context at a time (it owns the context's scratch batch)
     std::vector<size_t> lens(col_lens, col_lens + ncols);
     PlanDevice* pd = nullptr;
@@ -340,7 +340,7 @@ extern "C" {
 int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points, size_t* n_scalars, size_t* n_right_terms, size_t* n_instance_columns) {
     if (!ctx || !ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     // the layout does not depend on instance lengths; compile (or fetch) the plan for empty columns of the right count
-    std::vector<size_t> lens(ctx->vk->vk.num_instance_columns, 0);
+    std::vector<size_t> lens(ctx_total_instance_columns(ctx), 0);
     PlanDevice* pd = nullptr;
     int rc = ctx_get_plan(const_cast<h2v_ctx*>(ctx), lens, &pd);
     if (rc) return rc;
@@ -348,7 +348,7 @@ int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points,
     if (n_points) *n_points = pd->host.n_points;
     if (n_scalars) *n_scalars = pd->host.n_scalars;
     if (n_right_terms) *n_right_terms = pd->host.right_term_order.size();
-    if (n_instance_columns) *n_instance_columns = ctx->vk->vk.num_instance_columns;
+    if (n_instance_columns) *n_instance_columns = ctx_total_instance_columns(ctx);
     return 0;
 }
 
@@ -481,7 +481,7 @@ int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs
                             uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
     if (!ctx || (n && (!proofs || !proof_lens)) || (n && n_instance_columns && !col_lens_per_proof)) { set_last_error("h2v_verify_batch_shapes: null argument"); return H2V_ERR_BAD_ARGUMENT; }
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
-    if (n_instance_columns != ctx->vk->vk.num_instance_columns) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
+    if (n_instance_columns != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
     const size_t nc = n_instance_columns;
     std::vector<std::pair<std::vector<size_t>, std::vector<size_t>>> groups;   // (shape, proof indices) in first-appearance order
     for (size_t i = 0; i < n; ++i) {

@@ -24,11 +24,13 @@ struct h2v_ctx {
     hipStream_t stream = nullptr;  // used by the synchronous single-shot entry points
     std::mutex mu;                 // serialises the single-shot entry points
     h2v::VkDevice* vk = nullptr;   // per-VK compiled program and constants (vkplan.hip)
-    int multiopen = 0, transcript = 0;  // h2v_options
+    int multiopen = 0, transcript = 0, circuit_instances = 1;  // h2v_options
     struct h2v_batch* scratch_batch = nullptr;  // kept between one-shot calls (h2v_verify_batch / _each): ~20 device allocations saved per call
 };
 
 namespace h2v {
+// instance columns a proof of this context brings: circuit instances x the VK's instance columns (lib.rs:51-55)
+size_t ctx_total_instance_columns(const h2v_ctx* ctx);
 int ctx_load_vk(h2v_ctx* ctx, const uint8_t* vk, size_t vk_len, int vk_format);
 void ctx_release_vk(h2v_ctx* ctx);
 int affine_to_jacobian_enqueue(hipStream_t s, const G1A* d_in, G1J* d_out, uint32_t n);

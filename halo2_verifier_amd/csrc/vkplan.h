@@ -69,7 +69,7 @@ struct TranscriptSrc {  // one byte of the absorbed stream
     uint8_t kind; uint8_t value; uint32_t offset;
 };
 
-struct PlanOptions { int multiopen = 0; int transcript = 0; };  // h2v_options
+struct PlanOptions { int multiopen = 0; int transcript = 0; int circuit_instances = 1; };  // h2v_options
 
 struct Plan {
     PlanOptions opts;

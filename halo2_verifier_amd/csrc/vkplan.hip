@@ -290,8 +290,8 @@ struct Builder {
 
 enum CommitKind { K_ADVICE, K_PERM_PRODUCT, K_LOOKUP, K_SHUFFLE, K_FIXED, K_PERM_COMMON, K_H_MSM, K_RANDOM };
 struct CommitRef {
-    int kind, idx;
-    bool operator==(const CommitRef& o) const { return kind == o.kind && idx == o.idx; }
+    int kind, idx, inst;   // inst: the circuit instance the commitment belongs to (0 for the VK-wide ones)
+    bool operator==(const CommitRef& o) const { return kind == o.kind && idx == o.idx && inst == o.inst; }
 };
 struct SymQuery { CommitRef c; int64_t rot; Val eval; };  // point = x * omega^rot (rot normalised mod n)
 }  // namespace
@@ -301,7 +301,10 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     plan.opts = opts;
     const bool gwc = opts.multiopen == H2V_MULTIOPEN_GWC;
     if (opts.multiopen < 0 || opts.multiopen > 1 || opts.transcript < 0 || opts.transcript > 1) { err = "unknown multiopen / transcript option"; return H2V_ERR_BAD_ARGUMENT; }
-    if (col_lens.size() != vk.num_instance_columns) { err = "instances do not match the VK's instance column count"; return H2V_ERR_INVALID_INSTANCES; }
+    // M circuit instances share the transcript (`instances: &[&[&[Fr]]]`, lib.rs:33-55): col_lens is instance-major, M x columns
+    const size_t M = opts.circuit_instances > 0 ? (size_t)opts.circuit_instances : 1;
+    if (col_lens.size() != M * vk.num_instance_columns) { err = "instances do not match the VK's instance column count"; return H2V_ERR_INVALID_INSTANCES; }
+    const size_t NIC = vk.num_instance_columns;
     if (params.k != vk.k) { err = "params.k differs from vk.k"; return H2V_ERR_BAD_ARGUMENT; }
     const uint64_t n = 1ULL << vk.k;
     size_t total_inst = 0;
@@ -347,7 +350,8 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     auto norm_rot = [&](int64_t r) { int64_t m = (int64_t)n; return ((r % m) + m) % m; };
 
     // ---------------- proof layout + transcript stream
-    std::vector<uint32_t> advice_slot(A, 0), lk_input_slot(L), lk_table_slot(L), lk_product_slot(L), sh_slot(Sh), perm_slot(nsets), h_slot(H);
+    // point slots; the per-instance ones are indexed [m * count + i]
+    std::vector<uint32_t> advice_slot(M * A, 0), lk_input_slot(M * L), lk_table_slot(M * L), lk_product_slot(M * L), sh_slot(M * Sh), perm_slot(M * nsets), h_slot(H);
     uint32_t random_slot = 0;
     uint32_t np = 0, nsc = 0, off = 0;
     std::vector<uint32_t> squeeze_order;  // challenge id of each squeeze
@@ -386,38 +390,41 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         for (int i = 0; i < 32; ++i) emit_const(repr[i]);
         for (uint32_t v = 0; v < total_inst; ++v) { emit_const(2); for (uint32_t i = 0; i < 32; ++i) plan.stream.push_back({TranscriptSrc::INSTANCE, 0, v * 32 + i}); }
     }
-    for (unsigned phase = 0; phase <= max_phase; ++phase) {  // lib.rs:91-109
-        for (size_t i = 0; i < A; ++i) if (vk.advice_column_phase[i] == phase) advice_slot[i] = absorb_point();
+    for (unsigned phase = 0; phase <= max_phase; ++phase) {  // lib.rs:91-109: every instance's advice of the phase, then its challenges
+        for (size_t m = 0; m < M; ++m)
+            for (size_t i = 0; i < A; ++i) if (vk.advice_column_phase[i] == phase) advice_slot[m * A + i] = absorb_point();
         for (size_t i = 0; i < Ch; ++i) if (vk.challenge_phase[i] == phase) squeeze((uint32_t)i);
     }
     squeeze(C_THETA);
-    for (size_t i = 0; i < L; ++i) { lk_input_slot[i] = absorb_point(); lk_table_slot[i] = absorb_point(); }
+    for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < L; ++i) { lk_input_slot[m * L + i] = absorb_point(); lk_table_slot[m * L + i] = absorb_point(); }   // lib.rs:117-126
     squeeze(C_BETA); squeeze(C_GAMMA);
-    for (size_t i = 0; i < nsets; ++i) perm_slot[i] = absorb_point();
-    for (size_t i = 0; i < L; ++i) lk_product_slot[i] = absorb_point();
-    for (size_t i = 0; i < Sh; ++i) sh_slot[i] = absorb_point();
+    for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < nsets; ++i) perm_slot[m * nsets + i] = absorb_point();     // lib.rs:134-139
+    for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < L; ++i) lk_product_slot[m * L + i] = absorb_point();         // lib.rs:141-150
+    for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < Sh; ++i) sh_slot[m * Sh + i] = absorb_point();               // lib.rs:152-161
     random_slot = absorb_point();
     squeeze(C_Y);
     for (size_t i = 0; i < H; ++i) h_slot[i] = absorb_point();
     squeeze(C_X);
     // evaluations (lib.rs:220-253)
-    std::vector<uint32_t> s_adv(Qa), s_fix(Qf), s_sigma(P);
+    std::vector<uint32_t> s_adv(M * Qa), s_fix(Qf), s_sigma(P);   // advice evaluations: instance by instance (lib.rs:220-222)
     for (auto& s : s_adv) s = absorb_scalar();
     for (auto& s : s_fix) s = absorb_scalar();
     uint32_t s_random = absorb_scalar();
     for (auto& s : s_sigma) s = absorb_scalar();
     struct PS { uint32_t eval, next, last; bool has_last; };
-    std::vector<PS> s_perm(nsets);
-    for (size_t i = 0; i < nsets; ++i) {
-        s_perm[i].eval = absorb_scalar(); s_perm[i].next = absorb_scalar();
-        s_perm[i].has_last = i + 1 < nsets;
-        s_perm[i].last = s_perm[i].has_last ? absorb_scalar() : 0;
-    }
+    std::vector<PS> s_perm(M * nsets);
+    for (size_t m = 0; m < M; ++m)
+        for (size_t i = 0; i < nsets; ++i) {
+            PS& ps = s_perm[m * nsets + i];
+            ps.eval = absorb_scalar(); ps.next = absorb_scalar();
+            ps.has_last = i + 1 < nsets;
+            ps.last = ps.has_last ? absorb_scalar() : 0;
+        }
     struct LS { uint32_t product, product_next, input, input_inv, table; };
-    std::vector<LS> s_lk(L);
+    std::vector<LS> s_lk(M * L);
     for (auto& s : s_lk) { s.product = absorb_scalar(); s.product_next = absorb_scalar(); s.input = absorb_scalar(); s.input_inv = absorb_scalar(); s.table = absorb_scalar(); }
     struct SS { uint32_t product, product_next; };
-    std::vector<SS> s_sh(Sh);
+    std::vector<SS> s_sh(M * Sh);
     for (auto& s : s_sh) { s.product = absorb_scalar(); s.product_next = absorb_scalar(); }
     plan.n_main_points = np;
     plan.opening_offset = off;
@@ -427,6 +434,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     std::vector<uint32_t> gwc_w_slot;
     if (gwc) {
         auto seen = [&](int64_t r) { int64_t k2 = norm_rot(r); for (int64_t e : gwc_points) if (e == k2) return; gwc_points.push_back(k2); };
+        // (every instance contributes the same rotations in the same order, so the first-appearance order is instance 0's)
         for (const QueryH& q : vk.advice_queries) seen(q.rotation);
         if (nsets) { seen(0); seen(1); if (nsets > 1) seen(-(int64_t)(bf + 1)); }
         if (L) { seen(0); seen(-1); seen(1); }
@@ -467,14 +475,14 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     {
         size_t flat = 0; (void)flat;
         for (const QueryH& q : vk.instance_queries) {
-            if (q.column.index >= col_lens.size()) { err = "instance query names a missing column"; return H2V_ERR_FORMAT; }
-            if (!plan.wide_instances) for (size_t j = 0; j < col_lens[q.column.index]; ++j) need_l((int64_t)j - q.rotation);
+            if (q.column.index >= NIC) { err = "instance query names a missing column"; return H2V_ERR_FORMAT; }
+            if (!plan.wide_instances) for (size_t m = 0; m < M; ++m) for (size_t j = 0; j < col_lens[m * NIC + q.column.index]; ++j) need_l((int64_t)j - q.rotation);
         }
     }
 
     // ---------------- symbolic SHPLONK bookkeeping needs the query list; build evals first
-    std::vector<Val> advice_evals(Qa), fixed_evals(Qf), sigma_evals(P);
-    for (size_t i = 0; i < Qa; ++i) advice_evals[i] = b.load_scalar(s_adv[i]);
+    std::vector<Val> advice_evals_all(M * Qa), fixed_evals(Qf), sigma_evals(P);
+    for (size_t i = 0; i < M * Qa; ++i) advice_evals_all[i] = b.load_scalar(s_adv[i]);
     for (size_t i = 0; i < Qf; ++i) fixed_evals[i] = b.load_scalar(s_fix[i]);
     for (size_t i = 0; i < P; ++i) sigma_evals[i] = b.load_scalar(s_sigma[i]);
     Val random_eval = b.load_scalar(s_random);
@@ -483,39 +491,49 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     std::vector<SymQuery> queries;
     auto add_query = [&](CommitRef c, int64_t rot, Val e) { queries.push_back({c, norm_rot(rot), e}); };
     // (the eval Vals of h / instance-dependent values are patched after they exist; collect structure first)
-    for (size_t qi = 0; qi < Qa; ++qi) {
-        if (vk.advice_queries[qi].column.index >= A) { err = "advice query names a missing column"; return H2V_ERR_FORMAT; }
-        add_query({K_ADVICE, (int)vk.advice_queries[qi].column.index}, vk.advice_queries[qi].rotation, advice_evals[qi]);
-    }
-    std::vector<Val> pz(nsets), pz_next(nsets), pz_last(nsets);
-    for (size_t i = 0; i < nsets; ++i) { pz[i] = b.load_scalar(s_perm[i].eval); pz_next[i] = b.load_scalar(s_perm[i].next); if (s_perm[i].has_last) pz_last[i] = b.load_scalar(s_perm[i].last); }
-    for (size_t i = 0; i < nsets; ++i) { add_query({K_PERM_PRODUCT, (int)i}, 0, pz[i]); add_query({K_PERM_PRODUCT, (int)i}, 1, pz_next[i]); }
-    for (size_t i = nsets; i-- > 0;) { if (i + 1 == nsets) continue; add_query({K_PERM_PRODUCT, (int)i}, -(int64_t)(bf + 1), pz_last[i]); }
+    std::vector<Val> pz_all(M * nsets), pz_next_all(M * nsets), pz_last_all(M * nsets);
     struct LV { Val product, product_next, input, input_inv, table; };
-    std::vector<LV> lk(L);
-    for (size_t i = 0; i < L; ++i) {
-        lk[i] = {b.load_scalar(s_lk[i].product), b.load_scalar(s_lk[i].product_next), b.load_scalar(s_lk[i].input), b.load_scalar(s_lk[i].input_inv), b.load_scalar(s_lk[i].table)};
-        add_query({K_LOOKUP, (int)(3 * i + 0)}, 0, lk[i].product);
-        add_query({K_LOOKUP, (int)(3 * i + 1)}, 0, lk[i].input);
-        add_query({K_LOOKUP, (int)(3 * i + 2)}, 0, lk[i].table);
-        add_query({K_LOOKUP, (int)(3 * i + 1)}, -1, lk[i].input_inv);
-        add_query({K_LOOKUP, (int)(3 * i + 0)}, 1, lk[i].product_next);
-    }
+    std::vector<LV> lk_all(M * L);
     struct SV2 { Val product, product_next; };
-    std::vector<SV2> shv(Sh);
-    for (size_t i = 0; i < Sh; ++i) {
-        shv[i] = {b.load_scalar(s_sh[i].product), b.load_scalar(s_sh[i].product_next)};
-        add_query({K_SHUFFLE, (int)i}, 0, shv[i].product);
-        add_query({K_SHUFFLE, (int)i}, 1, shv[i].product_next);
+    std::vector<SV2> shv_all(M * Sh);
+    for (size_t m = 0; m < M; ++m) {   // lib.rs:349-391: per instance advice, permutation, lookups, shuffles
+        const int im = (int)m;
+        for (size_t qi = 0; qi < Qa; ++qi) {
+            if (vk.advice_queries[qi].column.index >= A) { err = "advice query names a missing column"; return H2V_ERR_FORMAT; }
+            add_query({K_ADVICE, (int)vk.advice_queries[qi].column.index, im}, vk.advice_queries[qi].rotation, advice_evals_all[m * Qa + qi]);
+        }
+        Val* pz = &pz_all[m * nsets]; Val* pz_next = &pz_next_all[m * nsets]; Val* pz_last = &pz_last_all[m * nsets];
+        for (size_t i = 0; i < nsets; ++i) {
+            const PS& ps = s_perm[m * nsets + i];
+            pz[i] = b.load_scalar(ps.eval); pz_next[i] = b.load_scalar(ps.next); if (ps.has_last) pz_last[i] = b.load_scalar(ps.last);
+        }
+        for (size_t i = 0; i < nsets; ++i) { add_query({K_PERM_PRODUCT, (int)i, im}, 0, pz[i]); add_query({K_PERM_PRODUCT, (int)i, im}, 1, pz_next[i]); }
+        for (size_t i = nsets; i-- > 0;) { if (i + 1 == nsets) continue; add_query({K_PERM_PRODUCT, (int)i, im}, -(int64_t)(bf + 1), pz_last[i]); }
+        for (size_t i = 0; i < L; ++i) {
+            const LS& ls = s_lk[m * L + i];
+            LV& e = lk_all[m * L + i];
+            e = {b.load_scalar(ls.product), b.load_scalar(ls.product_next), b.load_scalar(ls.input), b.load_scalar(ls.input_inv), b.load_scalar(ls.table)};
+            add_query({K_LOOKUP, (int)(3 * i + 0), im}, 0, e.product);
+            add_query({K_LOOKUP, (int)(3 * i + 1), im}, 0, e.input);
+            add_query({K_LOOKUP, (int)(3 * i + 2), im}, 0, e.table);
+            add_query({K_LOOKUP, (int)(3 * i + 1), im}, -1, e.input_inv);
+            add_query({K_LOOKUP, (int)(3 * i + 0), im}, 1, e.product_next);
+        }
+        for (size_t i = 0; i < Sh; ++i) {
+            SV2& e = shv_all[m * Sh + i];
+            e = {b.load_scalar(s_sh[m * Sh + i].product), b.load_scalar(s_sh[m * Sh + i].product_next)};
+            add_query({K_SHUFFLE, (int)i, im}, 0, e.product);
+            add_query({K_SHUFFLE, (int)i, im}, 1, e.product_next);
+        }
     }
     for (size_t qi = 0; qi < Qf; ++qi) {
         if (vk.fixed_queries[qi].column.index >= vk.fixed_commitments.size()) { err = "fixed query names a missing column"; return H2V_ERR_FORMAT; }
-        add_query({K_FIXED, (int)vk.fixed_queries[qi].column.index}, vk.fixed_queries[qi].rotation, fixed_evals[qi]);
+        add_query({K_FIXED, (int)vk.fixed_queries[qi].column.index, 0}, vk.fixed_queries[qi].rotation, fixed_evals[qi]);
     }
-    for (size_t i = 0; i < P; ++i) add_query({K_PERM_COMMON, (int)i}, 0, sigma_evals[i]);
+    for (size_t i = 0; i < P; ++i) add_query({K_PERM_COMMON, (int)i, 0}, 0, sigma_evals[i]);
     const size_t q_hmsm = queries.size();
-    add_query({K_H_MSM, 0}, 0, 0 /* patched: expected_h_eval */);
-    add_query({K_RANDOM, 0}, 0, random_eval);
+    add_query({K_H_MSM, 0, 0}, 0, 0 /* patched: expected_h_eval */);
+    add_query({K_RANDOM, 0, 0}, 0, random_eval);
 
     struct RotSet { std::vector<int64_t> rots; std::vector<CommitRef> commits; };
     std::vector<RotSet> rsets; std::set<int64_t> super;
@@ -548,25 +566,27 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     auto l_at = [&](int64_t r) { size_t i = l_index[norm_rot(r)]; return b.mul(b.mul(inv_list[3 + i], common), b.cst(omega_pow(l_rots[i]))); };
 
     // ---------------- instance evaluations (lib.rs:173-218): sum_j inst[col][j] * l_{j - rot}(x)
-    std::vector<Val> instance_evals;
+    std::vector<std::vector<Val>> instance_evals_all(M);
     {
         std::vector<uint32_t> col_base(col_lens.size(), 0);
         for (size_t c = 1; c < col_lens.size(); ++c) col_base[c] = col_base[c - 1] + (uint32_t)col_lens[c - 1];
         std::map<int64_t, Val> l_cache;
-        for (const QueryH& q : vk.instance_queries) {
-            if (plan.wide_instances) {   // evaluated by k_instance_eval before the program runs
-                plan.inst_queries.push_back({col_base[q.column.index], (uint32_t)col_lens[q.column.index], omega_pow(-(int64_t)q.rotation)});
-                instance_evals.push_back(b.load_insteval((uint32_t)plan.inst_queries.size() - 1));
-                continue;
+        for (size_t m = 0; m < M; ++m)
+            for (const QueryH& q : vk.instance_queries) {
+                const size_t col = m * NIC + q.column.index;
+                if (plan.wide_instances) {   // evaluated by k_instance_eval before the program runs
+                    plan.inst_queries.push_back({col_base[col], (uint32_t)col_lens[col], omega_pow(-(int64_t)q.rotation)});
+                    instance_evals_all[m].push_back(b.load_insteval((uint32_t)plan.inst_queries.size() - 1));
+                    continue;
+                }
+                Val acc = b.zero();
+                for (size_t j = 0; j < col_lens[col]; ++j) {
+                    int64_t r = norm_rot((int64_t)j - q.rotation);
+                    if (!l_cache.count(r)) l_cache[r] = l_at(r);
+                    acc = b.add(acc, b.mul(b.load_inst(col_base[col] + (uint32_t)j), l_cache[r]));
+                }
+                instance_evals_all[m].push_back(acc);
             }
-            Val acc = b.zero();
-            for (size_t j = 0; j < col_lens[q.column.index]; ++j) {
-                int64_t r = norm_rot((int64_t)j - q.rotation);
-                if (!l_cache.count(r)) l_cache[r] = l_at(r);
-                acc = b.add(acc, b.mul(b.load_inst(col_base[q.column.index] + (uint32_t)j), l_cache[r]));
-            }
-            instance_evals.push_back(acc);
-        }
     }
     // l_last, l_blind, l_0 (lib.rs:259-270)
     Val l_last = l_at(-(int64_t)(bf + 1));
@@ -576,79 +596,84 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
 
     // ---------------- expressions (lib.rs:273-346)
     const size_t Qi = vk.instance_queries.size();
-    std::map<std::pair<uint32_t, uint32_t>, Val> pow_cache;
     int expr_err = 0;
-    auto var_at = [&](uint32_t idx) -> Val {
-        if (idx < Qa) return advice_evals[idx];
-        if (idx < Qa + Qf) return fixed_evals[idx - Qa];
-        if (idx < Qa + Qf + Qi) return instance_evals[idx - Qa - Qf];
-        if (idx < Qa + Qf + Qi + Ch) return user_ch[idx - Qa - Qf - Qi];
-        expr_err = 1; return b.zero();  // "index out of range" panic (vk.rs:501)
-    };
-    auto eval_expr = [&](const ExprH& e) -> Val {
-        if (e.terms.empty()) { expr_err = 1; return b.zero(); }  // unwrap on empty terms (multilinear.rs:65)
-        Val sum = 0; bool first = true;
-        for (const TermH& t : e.terms) {
-            if (t.coeff_idx >= vk.coeff_vals.size()) { expr_err = 1; return b.zero(); }
-            Val prod = b.one();
-            for (const auto& f : t.factors) {
-                auto key = std::make_pair(f.first, f.second);
-                auto it = pow_cache.find(key);
-                Val pv = it != pow_cache.end() ? it->second : (pow_cache[key] = b.pow(var_at(f.first), f.second));
-                prod = b.mul(prod, pv);
-            }
-            Val term = b.mul(b.cst(vk.coeff_vals[t.coeff_idx]), prod);
-            sum = first ? term : b.add(sum, term);
-            first = false;
-        }
-        return sum;
-    };
     std::vector<Val> exprs;
-    for (const ExprH& g : vk.gates) exprs.push_back(eval_expr(g));
-    auto column_eval = [&](const ColumnH& c) -> Val {  // get_any_query_index(column, Rotation::cur()) (vk.rs:413-455)
-        const std::vector<QueryH>& qs = c.type <= 2 ? vk.advice_queries : (c.type == COL_FIXED ? vk.fixed_queries : vk.instance_queries);
-        for (size_t i = 0; i < qs.size(); ++i)
-            if (qs[i].column.index == c.index && qs[i].column.type == c.type && qs[i].rotation == 0)
-                return c.type <= 2 ? advice_evals[i] : (c.type == COL_FIXED ? fixed_evals[i] : instance_evals[i]);
-        expr_err = 1; return b.zero();
-    };
     Val active_rows = b.sub(b.one(), b.add(l_last, l_blind));
-    if (nsets > 0) {  // permutation.rs:189-288
-        exprs.push_back(b.mul(l_0, b.sub(b.one(), pz[0])));
-        exprs.push_back(b.mul(b.sub(b.sqr(pz[nsets - 1]), pz[nsets - 1]), l_last));
-        for (size_t i = 1; i < nsets; ++i) exprs.push_back(b.mul(b.sub(pz[i], pz_last[i - 1]), l_0));
-        Val beta_x = b.mul(beta, x);
-        for (size_t ci = 0; ci < nsets; ++ci) {
-            size_t lo = ci * chunk, hi = std::min(P, lo + chunk);
-            Val left = pz_next[ci], right = pz[ci];
-            Fr dpow = delta.pow_u32((uint32_t)(ci * chunk));
-            for (size_t j = lo; j < hi; ++j) {
-                Val v = column_eval(vk.permutation_columns[j]);
-                left = b.mul(left, b.add(b.add(v, b.mul(beta, sigma_evals[j])), gamma));
-                right = b.mul(right, b.add(b.add(v, b.mul(beta_x, b.cst(dpow))), gamma));
-                dpow = dpow * delta;
+    for (size_t m = 0; m < M; ++m) {   // lib.rs:273-346: flat_map over the instances — gates, permutation, lookups, shuffles of each
+        const Val* advice_evals = &advice_evals_all[m * Qa];
+        const std::vector<Val>& instance_evals = instance_evals_all[m];
+        std::map<std::pair<uint32_t, uint32_t>, Val> pow_cache;
+        auto var_at = [&](uint32_t idx) -> Val {
+            if (idx < Qa) return advice_evals[idx];
+            if (idx < Qa + Qf) return fixed_evals[idx - Qa];
+            if (idx < Qa + Qf + Qi) return instance_evals[idx - Qa - Qf];
+            if (idx < Qa + Qf + Qi + Ch) return user_ch[idx - Qa - Qf - Qi];
+            expr_err = 1; return b.zero();  // "index out of range" panic (vk.rs:501)
+        };
+        auto eval_expr = [&](const ExprH& e) -> Val {
+            if (e.terms.empty()) { expr_err = 1; return b.zero(); }  // unwrap on empty terms (multilinear.rs:65)
+            Val sum = 0; bool first = true;
+            for (const TermH& t : e.terms) {
+                if (t.coeff_idx >= vk.coeff_vals.size()) { expr_err = 1; return b.zero(); }
+                Val prod = b.one();
+                for (const auto& f : t.factors) {
+                    auto key = std::make_pair(f.first, f.second);
+                    auto it = pow_cache.find(key);
+                    Val pv = it != pow_cache.end() ? it->second : (pow_cache[key] = b.pow(var_at(f.first), f.second));
+                    prod = b.mul(prod, pv);
+                }
+                Val term = b.mul(b.cst(vk.coeff_vals[t.coeff_idx]), prod);
+                sum = first ? term : b.add(sum, term);
+                first = false;
             }
+            return sum;
+        };
+        for (const ExprH& g : vk.gates) exprs.push_back(eval_expr(g));
+        auto column_eval = [&](const ColumnH& c) -> Val {  // get_any_query_index(column, Rotation::cur()) (vk.rs:413-455)
+            const std::vector<QueryH>& qs = c.type <= 2 ? vk.advice_queries : (c.type == COL_FIXED ? vk.fixed_queries : vk.instance_queries);
+            for (size_t i = 0; i < qs.size(); ++i)
+                if (qs[i].column.index == c.index && qs[i].column.type == c.type && qs[i].rotation == 0)
+                    return c.type <= 2 ? advice_evals[i] : (c.type == COL_FIXED ? fixed_evals[i] : instance_evals[i]);
+            expr_err = 1; return b.zero();
+        };
+        const Val* pz = &pz_all[m * nsets]; const Val* pz_next = &pz_next_all[m * nsets]; const Val* pz_last = &pz_last_all[m * nsets];
+        if (nsets > 0) {  // permutation.rs:189-288
+            exprs.push_back(b.mul(l_0, b.sub(b.one(), pz[0])));
+            exprs.push_back(b.mul(b.sub(b.sqr(pz[nsets - 1]), pz[nsets - 1]), l_last));
+            for (size_t i = 1; i < nsets; ++i) exprs.push_back(b.mul(b.sub(pz[i], pz_last[i - 1]), l_0));
+            Val beta_x = b.mul(beta, x);
+            for (size_t ci = 0; ci < nsets; ++ci) {
+                size_t lo = ci * chunk, hi = std::min(P, lo + chunk);
+                Val left = pz_next[ci], right = pz[ci];
+                Fr dpow = delta.pow_u32((uint32_t)(ci * chunk));
+                for (size_t j = lo; j < hi; ++j) {
+                    Val v = column_eval(vk.permutation_columns[j]);
+                    left = b.mul(left, b.add(b.add(v, b.mul(beta, sigma_evals[j])), gamma));
+                    right = b.mul(right, b.add(b.add(v, b.mul(beta_x, b.cst(dpow))), gamma));
+                    dpow = dpow * delta;
+                }
+                exprs.push_back(b.mul(b.sub(left, right), active_rows));
+            }
+        }
+        auto compress = [&](const std::vector<ExprH>& es) { Val acc = b.zero(); for (const ExprH& e : es) acc = b.add(b.mul(acc, theta), eval_expr(e)); return acc; };
+        for (size_t i = 0; i < L; ++i) {  // lookup.rs:159-230
+            const LV& e = lk_all[m * L + i];
+            exprs.push_back(b.mul(l_0, b.sub(b.one(), e.product)));
+            exprs.push_back(b.mul(l_last, b.sub(b.sqr(e.product), e.product)));
+            Val left = b.mul(b.mul(e.product_next, b.add(e.input, beta)), b.add(e.table, gamma));
+            Val right = b.mul(b.mul(e.product, b.add(compress(vk.lookups[i].input), beta)), b.add(compress(vk.lookups[i].table), gamma));
+            exprs.push_back(b.mul(b.sub(left, right), active_rows));
+            exprs.push_back(b.mul(l_0, b.sub(e.input, e.table)));
+            exprs.push_back(b.mul(b.mul(b.sub(e.input, e.table), b.sub(e.input, e.input_inv)), active_rows));
+        }
+        for (size_t i = 0; i < Sh; ++i) {  // shuffle.rs:148-203
+            const SV2& e = shv_all[m * Sh + i];
+            exprs.push_back(b.mul(l_0, b.sub(b.one(), e.product)));
+            exprs.push_back(b.mul(l_last, b.sub(b.sqr(e.product), e.product)));
+            Val left = b.mul(e.product_next, b.add(compress(vk.shuffles[i].shuffle), gamma));
+            Val right = b.mul(e.product, b.add(compress(vk.shuffles[i].input), gamma));
             exprs.push_back(b.mul(b.sub(left, right), active_rows));
         }
-    }
-    auto compress = [&](const std::vector<ExprH>& es) { Val acc = b.zero(); for (const ExprH& e : es) acc = b.add(b.mul(acc, theta), eval_expr(e)); return acc; };
-    for (size_t i = 0; i < L; ++i) {  // lookup.rs:159-230
-        const LV& e = lk[i];
-        exprs.push_back(b.mul(l_0, b.sub(b.one(), e.product)));
-        exprs.push_back(b.mul(l_last, b.sub(b.sqr(e.product), e.product)));
-        Val left = b.mul(b.mul(e.product_next, b.add(e.input, beta)), b.add(e.table, gamma));
-        Val right = b.mul(b.mul(e.product, b.add(compress(vk.lookups[i].input), beta)), b.add(compress(vk.lookups[i].table), gamma));
-        exprs.push_back(b.mul(b.sub(left, right), active_rows));
-        exprs.push_back(b.mul(l_0, b.sub(e.input, e.table)));
-        exprs.push_back(b.mul(b.mul(b.sub(e.input, e.table), b.sub(e.input, e.input_inv)), active_rows));
-    }
-    for (size_t i = 0; i < Sh; ++i) {  // shuffle.rs:148-203
-        const SV2& e = shv[i];
-        exprs.push_back(b.mul(l_0, b.sub(b.one(), e.product)));
-        exprs.push_back(b.mul(l_last, b.sub(b.sqr(e.product), e.product)));
-        Val left = b.mul(e.product_next, b.add(compress(vk.shuffles[i].shuffle), gamma));
-        Val right = b.mul(e.product, b.add(compress(vk.shuffles[i].input), gamma));
-        exprs.push_back(b.mul(b.sub(left, right), active_rows));
     }
     if (expr_err) { err = "the VK makes the reference panic (empty expression polynomial or out-of-range index)"; return H2V_ERR_REFERENCE_PANIC; }
     // vanishing.rs:92-121
@@ -673,10 +698,10 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     plan.shared_bases.push_back(params.g);
     auto slot_of = [&](const CommitRef& c) -> std::pair<uint8_t, uint32_t> {  // (is_shared, index)
         switch (c.kind) {
-            case K_ADVICE: return {0, advice_slot[c.idx]};
-            case K_PERM_PRODUCT: return {0, perm_slot[c.idx]};
-            case K_LOOKUP: return {0, c.idx % 3 == 0 ? lk_product_slot[c.idx / 3] : (c.idx % 3 == 1 ? lk_input_slot[c.idx / 3] : lk_table_slot[c.idx / 3])};
-            case K_SHUFFLE: return {0, sh_slot[c.idx]};
+            case K_ADVICE: return {0, advice_slot[c.inst * A + c.idx]};
+            case K_PERM_PRODUCT: return {0, perm_slot[c.inst * nsets + c.idx]};
+            case K_LOOKUP: return {0, c.idx % 3 == 0 ? lk_product_slot[c.inst * L + c.idx / 3] : (c.idx % 3 == 1 ? lk_input_slot[c.inst * L + c.idx / 3] : lk_table_slot[c.inst * L + c.idx / 3])};
+            case K_SHUFFLE: return {0, sh_slot[c.inst * Sh + c.idx]};
             case K_FIXED: return {1, (uint32_t)c.idx};
             case K_PERM_COMMON: return {1, (uint32_t)(F + c.idx)};
             case K_RANDOM: return {0, random_slot};
@@ -837,6 +862,7 @@ int ctx_load_vk(h2v_ctx* ctx, const uint8_t* vk, size_t vk_len, int vk_format) {
     ctx->vk = v;
     return 0;
 }
+size_t ctx_total_instance_columns(const h2v_ctx* ctx) { return ctx->vk ? (size_t)ctx->circuit_instances * ctx->vk->vk.num_instance_columns : 0; }
 void ctx_release_vk(h2v_ctx* ctx) {
     if (!ctx->vk) return;
     for (auto& kv : ctx->vk->plans) { kv.second->release(); delete kv.second; }
@@ -850,7 +876,7 @@ int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice**
     if (it != ctx->vk->plans.end()) { *out = it->second; return 0; }
     PlanDevice* pd = new PlanDevice();
     std::string err;
-    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript;
+    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript; po.circuit_instances = ctx->circuit_instances;
     int rc = compile_plan(ctx->vk->vk, ctx->params, col_lens, po, pd->host, err);
     if (rc) { set_last_error("plan: " + err); delete pd; return rc; }
     H2V_HIP_CHECK(hipSetDevice(ctx->device));

@@ -45,7 +45,7 @@ class TranscriptKind(enum.IntEnum):  # the `T: TranscriptRead` parameter (lib.rs
 
 
 class _Options(ctypes.Structure):
-    _fields_ = [("multiopen", ctypes.c_int), ("transcript", ctypes.c_int)]
+    _fields_ = [("multiopen", ctypes.c_int), ("transcript", ctypes.c_int), ("circuit_instances", ctypes.c_int)]
 
 
 class ParamsKZG:
@@ -136,11 +136,15 @@ class Context:
     """ParamsKZG + VerifyingKey resident on one GPU (h2v_ctx)."""
 
     def __init__(self, params: ParamsKZG, vk: VerifyingKey = None, device: int = 0, multiopen=MultiOpen.SHPLONK,
-                 transcript=TranscriptKind.Blake2b):
+                 transcript=TranscriptKind.Blake2b, circuit_instances: int = 1):
+        """circuit_instances = len(instances) of the reference's verify_proof (`instances: &[&[&[Fr]]]`, lib.rs:43): how many
+        circuit instances share one proof transcript.  With M > 1 the `instances` of a proof is the list of its M x columns,
+        instance by instance."""
         self._lib = _lib.load_library()
         self._h = ctypes.c_void_p()
         vkb = vk.data if vk is not None else None
-        opts = _Options(int(multiopen), int(transcript))
+        opts = _Options(int(multiopen), int(transcript), int(circuit_instances))
+        self.circuit_instances = int(circuit_instances)
         check(self._lib.h2v_ctx_create_ex(params.data, len(params.data), int(params.format), vkb, len(vkb) if vkb else 0,
                                           int(vk.format) if vk is not None else 0, device, ctypes.byref(opts), ctypes.byref(self._h)))
         self.params, self.vk, self.device = params, vk, device
@@ -253,9 +257,9 @@ class _Strategy:
 class AccumulatorStrategy(_Strategy):
     """poly/kzg/strategy.rs:55-79,125-140: collects proofs; finalize() = one pairing for all of them."""
 
-    def __init__(self, params, rand=None, device=0):
+    def __init__(self, params, rand=None, device=0, circuit_instances=1):
         super().__init__(params)
-        self.rand, self.device = rand, device
+        self.rand, self.device, self.circuit_instances = rand, device, circuit_instances
 
     def finalize(self) -> bool:
         """One pairing for everything that was accumulated.  verify_proof takes a VK per call and one strategy may accumulate
@@ -273,7 +277,7 @@ class AccumulatorStrategy(_Strategy):
         for i, (vk, _, _) in enumerate(self._items):
             groups.setdefault((vk.data, int(vk.format)), []).append(i)
         if len(groups) == 1:
-            ctx = Context(self.params, self._items[0][0], self.device)
+            ctx = Context(self.params, self._items[0][0], self.device, circuit_instances=self.circuit_instances)
             try:
                 ok, _, _, _ = ctx.verify_batch([p for _, _, p in self._items], [i for _, i, _ in self._items], rand)
                 return ok
@@ -295,7 +299,7 @@ class AccumulatorStrategy(_Strategy):
         ctxs, ok_all = {}, True
         try:
             for key, idx in groups.items():
-                ctx = ctxs[key] = Context(self.params, self._items[idx[0]][0], self.device)
+                ctx = ctxs[key] = Context(self.params, self._items[idx[0]][0], self.device, circuit_instances=self.circuit_instances)
                 for i in idx:
                     _, inst, proof = self._items[i]
                     flat, lens = _flatten_instances(inst)
@@ -320,16 +324,18 @@ class AccumulatorStrategy(_Strategy):
 class SingleStrategy(_Strategy):
     """poly/kzg/strategy.rs:83-102,164-176: one pairing per proof, checked inside verify_proof."""
 
-    def __init__(self, params, device=0):
+    def __init__(self, params, device=0, circuit_instances=1):
         super().__init__(params)
-        self.device = device
+        self.device, self.circuit_instances = device, circuit_instances
 
 
 def verify_proof(params: ParamsKZG, vk: VerifyingKey, strategy, instances, proof: bytes):
-    """lib.rs:33-49.  `instances` = one circuit instance: list of columns.  With SingleStrategy returns None or
-    raises H2VError(code = PlonkError); with AccumulatorStrategy returns the strategy (Output = Self)."""
+    """lib.rs:33-49.  `instances` = one circuit instance: list of columns — or, for a strategy created with circuit_instances = M,
+    the M x columns of the M instances that share the transcript, instance by instance (the reference's `&[&[&[Fr]]]` flattened).
+    With SingleStrategy returns None or raises H2VError(code = PlonkError); with AccumulatorStrategy returns the strategy
+    (Output = Self)."""
     if isinstance(strategy, SingleStrategy):
-        ctx = Context(params, vk, strategy.device)
+        ctx = Context(params, vk, strategy.device, circuit_instances=strategy.circuit_instances)
         try:
             st = ctx.verify_each([proof], [instances])[0]
         finally:

@@ -71,8 +71,13 @@ int h2v_ctx_create(const uint8_t* params, size_t params_len, int params_format,
 /* The two generic parameters of the reference's verify_proof that change what is computed (lib.rs:33-40):
  *   multiopen:  0 = VerifierSHPLONK (poly/kzg/multiopen/shplonk.rs), 1 = VerifierGWC (poly/kzg/multiopen/gwc.rs)
  *   transcript: 0 = Blake2bRead, 1 = Keccak256Read (transcript/mod.rs:104-116)
- * h2v_ctx_create == h2v_ctx_create_ex with {0, 0}. */
-typedef struct h2v_options { int multiopen; int transcript; } h2v_options;
+ * and the length of its `instances: &[&[&[Fr]]]` argument (lib.rs:43,51-55,63):
+ *   circuit_instances: how many circuit instances share ONE proof transcript (0 or 1 = one, what every caller inside the reference
+ *                      passes).  With M > 1 a proof carries M sets of advice / permutation / lookup / shuffle commitments and
+ *                      evaluations in the reference's interleaved order (lib.rs:91-161, 220-253), and every entry point below takes
+ *                      n_instance_columns = M x the VK's instance columns, col_lens and instances32 instance-major.
+ * h2v_ctx_create == h2v_ctx_create_ex with {0, 0, 1}. */
+typedef struct h2v_options { int multiopen; int transcript; int circuit_instances; } h2v_options;
 #define H2V_MULTIOPEN_SHPLONK 0
 #define H2V_MULTIOPEN_GWC 1
 #define H2V_TRANSCRIPT_BLAKE2B 0
@@ -98,10 +103,10 @@ int h2v_pairing_check(h2v_ctx* ctx, const uint8_t left_xy[64], const uint8_t rig
 /* N x verify_proof under AccumulatorStrategy, then finalize():
  *   replaces: the loop  s = verify_proof(&params, &vk, s, instances_i, &mut Blake2bRead::init(proof_i))?
  *             followed by s.finalize()   (lib.rs:33-425, poly/kzg/strategy.rs:125-140).
- * proofs[i] / proof_lens[i]: proof byte strings.  Instances: one circuit instance per proof
- * (instances.len() == 1 in the reference's terms); instances32[i] is the concatenation of that
- * proof's instance columns, col_lens[c] the number of values in column c (same for every proof
- * of the batch), n_instance_columns must equal the VK's (else H2V_ERR_INVALID_INSTANCES).
+ * proofs[i] / proof_lens[i]: proof byte strings.  Instances: instances32[i] is the concatenation of proof i's instance
+ * columns — of all its circuit instances, instance by instance, when the context was created with circuit_instances > 1 —
+ * col_lens[c] the number of values in column c (same for every proof of the batch; h2v_verify_batch_shapes lifts that),
+ * n_instance_columns must equal circuit_instances x the VK's instance columns (else H2V_ERR_INVALID_INSTANCES, lib.rs:51-55).
  * rand32: the n scalars that AccumulatorStrategy::process draws with Fr::random
  * (kzg/strategy.rs:129), in call order; NULL = draw from the OS RNG.
  * per_proof_status[i]: 0 or the plonk::Error the reference's verify_proof returns for proof i;

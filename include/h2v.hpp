@@ -62,7 +62,7 @@ struct VerifyingKey { Bytes bytes; SerdeFormat format = SerdeFormat::RawBytes; }
 class Context {
 public:
     Context(const ParamsKZG& p, const VerifyingKey& vk, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b) {
-        h2v_options o{(int)mo, (int)tr};
+        h2v_options o{(int)mo, (int)tr, 1};
         check(h2v_ctx_create_ex(p.bytes.data(), p.bytes.size(), (int)p.format, vk.bytes.data(), vk.bytes.size(), (int)vk.format, device, &o, &h_));
     }
     ~Context() { if (h_) h2v_ctx_destroy(h_); }

@@ -44,6 +44,18 @@ size_t copy_out(const std::vector<uint8_t>& v, uint8_t* buf, size_t cap) {
 }  // namespace
 
 static thread_local VerifyOptions g_opts;
+static thread_local size_t g_circuit_instances = 1;   // h2o_set_circuit_instances: `instances.len()` of the verifier-side calls
+namespace {
+// ncols = M x (columns per circuit instance), instance-major: the reference's `instances: &[&[&[Fr]]]` flattened
+std::vector<std::vector<std::vector<Fr>>> parse_multi(const uint8_t* inst32, const size_t* col_lens, size_t ncols) {
+    const size_t M = g_circuit_instances ? g_circuit_instances : 1, per = ncols / M;
+    std::vector<std::vector<std::vector<Fr>>> out(M, std::vector<std::vector<Fr>>(per));
+    size_t off = 0;
+    for (size_t c = 0; c < M * per; ++c)
+        for (size_t i = 0; i < col_lens[c]; ++i, ++off) { Fr v; Fr::from_bytes(inst32 + 32 * off, v); out[c / per][c % per].push_back(v); }
+    return out;
+}
+}  // namespace
 
 extern "C" {
 
@@ -96,7 +108,10 @@ int h2o_verify_single(const uint8_t* params, size_t plen, int pfmt, const uint8_
     try {
         ParamsKZG p = read_params(params, plen, (SerdeFormat)pfmt);
         VerifyingKey vk = read_vk(vkb, vlen, (SerdeFormat)vfmt);
-        return verify_single(p, vk, parse_instances(inst32, col_lens, ncols), proof, proof_len, g_opts);
+        DualMSM msm;
+        Error e = verify_proof_multi(p, vk, parse_multi(inst32, col_lens, ncols), proof, proof_len, msm, nullptr, nullptr, g_opts);
+        if (e != OK) return e;
+        return msm.check(p) ? OK : ConstraintSystemFailure;   // SingleStrategy (strategy.rs:164-176)
     } catch (...) { return -100; }
 }
 
@@ -111,7 +126,7 @@ int h2o_guard_msm(const uint8_t* params, size_t plen, int pfmt, const uint8_t* v
         ParamsKZG p = read_params(params, plen, (SerdeFormat)pfmt);
         VerifyingKey vk = read_vk(vkb, vlen, (SerdeFormat)vfmt);
         DualMSM acc; VerifyTrace t;
-        Error e = verify_proof(p, vk, parse_instances(inst32, col_lens, ncols), proof, proof_len, acc, &t, nullptr, g_opts);
+        Error e = verify_proof_multi(p, vk, parse_multi(inst32, col_lens, ncols), proof, proof_len, acc, &t, nullptr, g_opts);
         if (e != OK) return e;
         size_t cap_r = *n_right, cap_l = *n_left;
         *n_right = acc.right.scalars.size(); *n_left = acc.left.scalars.size();
@@ -145,7 +160,8 @@ int h2o_verify_batch(const uint8_t* params, size_t plen, int pfmt, const uint8_t
         for (size_t i = 0; i < n; ++i) {
             Fr r; if (!Fr::from_bytes(rand32 + 32 * i, r)) return -1;
             DualMSM saved = st.acc;
-            Error e = st.process(p, vk, parse_instances(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, r, g_opts);
+            st.acc.scale(r);  // strategy.rs:129 — before the closure runs
+            Error e = verify_proof_multi(p, vk, parse_multi(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, st.acc, nullptr, nullptr, g_opts);
             statuses[i] = e;
             if (e != OK) { all_ok = false; saved.scale(r); st.acc = saved; }
         }
@@ -165,7 +181,9 @@ int h2o_verify_each(const uint8_t* params, size_t plen, int pfmt, const uint8_t*
         size_t per = 0; for (size_t c = 0; c < ncols; ++c) per += col_lens[c];
         int acc = 0;
         for (size_t i = 0; i < n; ++i) {
-            statuses[i] = verify_single(p, vk, parse_instances(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, g_opts);
+            DualMSM msm;
+            Error e = verify_proof_multi(p, vk, parse_multi(inst32 + 32 * per * i, col_lens, ncols), proofs + proof_len * i, proof_len, msm, nullptr, nullptr, g_opts);
+            statuses[i] = e != OK ? e : (msm.check(p) ? OK : ConstraintSystemFailure);
             acc += statuses[i] == OK;
         }
         return acc;
@@ -196,6 +214,8 @@ void h2o_setup_free(void* h) { delete (Setup*)h; }
 void h2o_setup_set_options(void* h, int multiopen, int transcript) { ((Setup*)h)->multiopen = multiopen; ((Setup*)h)->transcript = transcript; }
 // verifier-side options for every h2o_verify_* / h2o_guard_msm call of this thread (0/0 = SHPLONK + Blake2b)
 void h2o_set_verify_options(int multiopen, int transcript) { g_opts.multiopen = multiopen; g_opts.transcript = transcript; }
+// `instances.len()` for every h2o_verify_* / h2o_guard_msm call of this thread: their ncols / col_lens then describe M x columns
+void h2o_set_circuit_instances(size_t m) { g_circuit_instances = m ? m : 1; }
 size_t h2o_setup_vk(void* h, int fmt, uint8_t* buf, size_t cap) { return copy_out(write_vk(((Setup*)h)->pk.vk, (SerdeFormat)fmt), buf, cap); }
 size_t h2o_setup_params(void* h, int fmt, uint8_t* buf, size_t cap) { return copy_out(write_params(((Setup*)h)->ck.params, (SerdeFormat)fmt), buf, cap); }
 
@@ -222,6 +242,23 @@ size_t h2o_prove_vector_mul_len(void* h, const uint8_t* a32, const uint8_t* b32,
     }
     Rng rng(rng_seed);
     return copy_out(create_proof(s->pk, s->ck, {c}, witness_vector_mul(a, b), rng, s->multiopen, s->transcript), proof, cap);
+}
+// M circuit instances in ONE transcript: a32 / b32 hold M x n_mul scalars, instances_out receives the M x n_mul products
+size_t h2o_prove_vector_mul_multi(void* h, size_t M, const uint8_t* a32, const uint8_t* b32, uint64_t rng_seed, uint8_t* proof, size_t cap, uint8_t* instances_out) {
+    Setup* s = (Setup*)h;
+    std::vector<std::vector<std::vector<Fr>>> insts(M);
+    std::vector<WitnessFn> ws;
+    for (size_t q = 0; q < M; ++q) {
+        std::vector<Fr> a(s->n_mul), b(s->n_mul), c(s->n_mul);
+        for (size_t i = 0; i < s->n_mul; ++i) {
+            Fr::from_bytes(a32 + 32 * (q * s->n_mul + i), a[i]); Fr::from_bytes(b32 + 32 * (q * s->n_mul + i), b[i]); c[i] = a[i] * b[i];
+            if (instances_out) c[i].to_bytes(instances_out + 32 * (q * s->n_mul + i));
+        }
+        insts[q] = {c};
+        ws.push_back(witness_vector_mul(a, b));
+    }
+    Rng rng(rng_seed);
+    return copy_out(create_proof_multi(s->pk, s->ck, insts, ws, rng, s->multiopen, s->transcript), proof, cap);
 }
 // batch of `count` distinct proofs with pseudo-random a, b derived from seed+i; nthreads workers
 size_t h2o_prove_vector_mul_batch(void* h, size_t count, uint64_t seed, unsigned nthreads, uint8_t* proofs, size_t proof_len, uint8_t* instances_out) {
@@ -256,6 +293,42 @@ size_t h2o_prove_shuffle(void* h, uint64_t data_seed, int break_it, uint64_t rng
     if (break_it) std::swap(shuf[0][0], shuf[0][1]);
     Rng rng(rng_seed);
     return copy_out(create_proof(s->pk, s->ck, {}, witness_two_phase_shuffle(orig, shuf), rng, s->multiopen, s->transcript), proof, cap);
+}
+// M shuffles in one transcript (data_seed + q each); break_at in [0, M) breaks that instance's shuffle, -1 none
+size_t h2o_prove_shuffle_multi(void* h, size_t M, uint64_t data_seed, int break_at, uint64_t rng_seed, uint8_t* proof, size_t cap) {
+    Setup* s = (Setup*)h;
+    std::vector<WitnessFn> ws;
+    for (size_t q = 0; q < M; ++q) {
+        Rng dr(data_seed + 1000003ULL * q);
+        std::vector<std::vector<Fr>> orig(s->W, std::vector<Fr>(s->H)), shuf;
+        for (auto& col : orig) for (auto& v : col) v = dr.fr();
+        shuf = orig;
+        for (size_t row = s->H - 1; row >= 1; --row) { size_t r = dr.next() % row; for (auto& col : shuf) std::swap(col[row], col[r]); }
+        if ((int)q == break_at) std::swap(shuf[0][0], shuf[0][1]);
+        ws.push_back(witness_two_phase_shuffle(orig, shuf));
+    }
+    Rng rng(rng_seed);
+    return copy_out(create_proof_multi(s->pk, s->ck, std::vector<std::vector<std::vector<Fr>>>(M), ws, rng, s->multiopen, s->transcript), proof, cap);
+}
+// M instances of the wide circuit in one transcript (witness_seed + q each); tamper_at in [0, M) corrupts one lookup input cell
+// of that instance, -1 none; instances_out receives M x 8 public inputs
+size_t h2o_prove_wide_multi(void* h, size_t M, uint64_t witness_seed, int tamper_at, uint64_t rng_seed, uint8_t* proof, size_t cap, uint8_t* instances_out) {
+    Setup* s = (Setup*)h;
+    const Circuit& c = s->pk.circuit;
+    std::vector<std::vector<std::vector<Fr>>> insts(M);
+    std::vector<WitnessFn> ws;
+    for (size_t q = 0; q < M; ++q) {
+        WitnessFn base = witness_wide(c, witness_seed + 7919ULL * q);
+        std::vector<std::vector<Fr>> scratch(c.cs.num_advice_columns, std::vector<Fr>(c.n(), Fr::zero()));
+        base(0, {}, scratch);
+        std::vector<Fr> inst(8);
+        for (size_t i = 0; i < 8; ++i) { inst[i] = scratch[2][i + 1]; if (instances_out) inst[i].to_bytes(instances_out + 32 * (8 * q + i)); }
+        insts[q] = {inst};
+        if ((int)q == tamper_at) ws.push_back([base](unsigned ph, const std::vector<Fr>& ch, std::vector<std::vector<Fr>>& adv) { base(ph, ch, adv); if (ph == 0) adv[1][5] = adv[1][5] + Fr::from_u64(123456789); });
+        else ws.push_back(base);
+    }
+    Rng rng(rng_seed);
+    return copy_out(create_proof_multi(s->pk, s->ck, insts, ws, rng, s->multiopen, s->transcript), proof, cap);
 }
 // wide circuit: instances_out receives the 8 public inputs; tamper != 0 corrupts one lookup input cell
 size_t h2o_prove_wide(void* h, uint64_t witness_seed, int tamper, uint64_t rng_seed, uint8_t* proof, size_t cap, uint8_t* instances_out) {

@@ -227,31 +227,58 @@ std::vector<Fr> interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& v
 }
 }  // namespace
 
+// One circuit instance's share of the prover state (the reference's verifier loops over `num_proofs` of these inside one
+// transcript, lib.rs:63-161,220-253)
+struct InstState {
+    std::vector<std::vector<Fr>> inst, advice;
+    std::vector<std::vector<Fr>> lkA, lkS, lkAp, lkSp, lkZ, permZ, shA, shS, shZ;
+    std::vector<std::vector<Fr>> adv_c, inst_c, pz_c, lkAp_c, lkSp_c, lkZ_c, shZ_c;
+    std::vector<std::vector<Fr>> adv_e, inst_e, pz_e, lkAp_e, lkSp_e, lkZ_e, shZ_e;
+    std::vector<VarSrc> row_vars, ext_vars;
+    std::vector<Fr> adv_evals;
+    std::vector<std::array<Fr, 3>> pz_ev;
+    std::vector<std::array<Fr, 5>> lk_ev;
+    std::vector<std::array<Fr, 2>> sh_ev;
+};
+
 std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, const std::vector<std::vector<Fr>>& instances,
                                   const WitnessFn& witness, Rng& rng, int multiopen, int transcript) {
+    return create_proof_multi(pk, ck, {instances}, {witness}, rng, multiopen, transcript);
+}
+
+// `instances[m]` / `witnesses[m]`: circuit instance m of the transcript (`instances: &[&[&[Fr]]]`, lib.rs:33-49).  Every step
+// that the verifier repeats per instance is written per instance in the same order (lib.rs:91-161, 220-253, 349-391).
+std::vector<uint8_t> create_proof_multi(const ProvingKey& pk, const CommitKey& ck, const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                        const std::vector<WitnessFn>& witnesses, Rng& rng, int multiopen, int transcript) {
     const Circuit& c = pk.circuit; const ConstraintSystem& cs = c.cs;
     const size_t n = c.n(), u = c.usable_rows(), bf = cs.blinding_factors();
     const uint32_t k = c.k, ek = pk.ext_k;
     const size_t m = (size_t)1 << ek, stride = m / n;
+    const size_t M = instances.size();
     const Ntt& nt = ntt_ctx(k);
     const Fr omega = nt.omega, omega_inv = omega.inv();
     TranscriptWrite tr(transcript);
     tr.common_scalar(pk.vk.transcript_repr);
-    for (const auto& col : instances) for (const Fr& v : col) tr.common_scalar(v);
+    for (const auto& one : instances) for (const auto& col : one) for (const Fr& v : col) tr.common_scalar(v);
 
+    std::vector<InstState> S(M);
     // instance columns as Lagrange polynomials
-    std::vector<std::vector<Fr>> inst(cs.num_instance_columns, std::vector<Fr>(n, Fr::zero()));
-    for (size_t j = 0; j < inst.size(); ++j) for (size_t i = 0; i < instances[j].size(); ++i) inst[j][i] = instances[j][i];
+    for (size_t q = 0; q < M; ++q) {
+        S[q].inst.assign(cs.num_instance_columns, std::vector<Fr>(n, Fr::zero()));
+        for (size_t j = 0; j < S[q].inst.size(); ++j) for (size_t i = 0; i < instances[q][j].size(); ++i) S[q].inst[j][i] = instances[q][j][i];
+        S[q].advice.assign(cs.num_advice_columns, std::vector<Fr>(n, Fr::zero()));
+    }
 
-    // phases
-    std::vector<std::vector<Fr>> advice(cs.num_advice_columns, std::vector<Fr>(n, Fr::zero()));
+    // phases: the advice commitments of every instance, then the phase's challenges
     std::vector<Fr> challenges(cs.num_challenges, Fr::zero());
     for (unsigned phase = 0; phase <= cs.max_phase(); ++phase) {
-        witness(phase, challenges, advice);
-        for (size_t j = 0; j < cs.num_advice_columns; ++j) {
-            if (cs.advice_column_phase[j] != phase) continue;
-            for (size_t i = u; i < n; ++i) advice[j][i] = rng.fr();
-            tr.write_point(ck.commit_lagrange(advice[j]));
+        for (size_t q = 0; q < M; ++q) {
+            witnesses[q](phase, challenges, S[q].advice);
+            for (size_t j = 0; j < cs.num_advice_columns; ++j) {
+                if (cs.advice_column_phase[j] != phase) continue;
+                for (size_t i = u; i < n; ++i) S[q].advice[j][i] = rng.fr();
+                tr.write_point(ck.commit_lagrange(S[q].advice[j]));
+            }
         }
         for (size_t j = 0; j < cs.num_challenges; ++j) if (cs.challenge_phase[j] == phase) challenges[j] = tr.squeeze_challenge();
     }
@@ -265,10 +292,10 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
         for (const Fr& ch : challenges) vars.push_back({nullptr, 0, ch});
         return vars;
     };
-    std::vector<VarSrc> row_vars = make_vars(advice, c.fixed, inst);
+    for (size_t q = 0; q < M; ++q) S[q].row_vars = make_vars(S[q].advice, c.fixed, S[q].inst);
 
     Fr theta = tr.squeeze_challenge();
-    auto compress_rows = [&](const std::vector<ExprPoly>& es) {
+    auto compress_rows = [&](const std::vector<VarSrc>& row_vars, const std::vector<ExprPoly>& es) {
         std::vector<Fr> out(n, Fr::zero());
         for (size_t i = 0; i < n; ++i) {
             Fr acc = Fr::zero();
@@ -279,32 +306,35 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
     };
     // lookups: permuted input / table columns
     size_t L = cs.lookups.size(), Sh = cs.shuffles.size();
-    std::vector<std::vector<Fr>> lkA(L), lkS(L), lkAp(L), lkSp(L), lkZ(L);
-    for (size_t l = 0; l < L; ++l) {
-        lkA[l] = compress_rows(cs.lookups[l].input);
-        lkS[l] = compress_rows(cs.lookups[l].table);
-        std::vector<Fr> a(lkA[l].begin(), lkA[l].begin() + u);
-        std::sort(a.begin(), a.end(), FrLess());
-        // S': a "new" value of A' takes the matching table entry; repeats take whatever is left over
-        std::multimap<Fr, int, FrLess> leftover;
-        for (size_t i = 0; i < u; ++i) leftover.emplace(lkS[l][i], 0);
-        std::vector<Fr> sp(u); std::vector<size_t> holes;
-        for (size_t i = 0; i < u; ++i) {
-            if (i == 0 || !(a[i] == a[i - 1])) {
-                sp[i] = a[i];
-                auto it = leftover.find(a[i]);
-                if (it != leftover.end()) leftover.erase(it);  // absent => invalid witness; the proof will be rejected
-            } else holes.push_back(i);
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        T.lkA.resize(L); T.lkS.resize(L); T.lkAp.resize(L); T.lkSp.resize(L); T.lkZ.resize(L);
+        for (size_t l = 0; l < L; ++l) {
+            T.lkA[l] = compress_rows(T.row_vars, cs.lookups[l].input);
+            T.lkS[l] = compress_rows(T.row_vars, cs.lookups[l].table);
+            std::vector<Fr> a(T.lkA[l].begin(), T.lkA[l].begin() + u);
+            std::sort(a.begin(), a.end(), FrLess());
+            // S': a "new" value of A' takes the matching table entry; repeats take whatever is left over
+            std::multimap<Fr, int, FrLess> leftover;
+            for (size_t i = 0; i < u; ++i) leftover.emplace(T.lkS[l][i], 0);
+            std::vector<Fr> sp(u); std::vector<size_t> holes;
+            for (size_t i = 0; i < u; ++i) {
+                if (i == 0 || !(a[i] == a[i - 1])) {
+                    sp[i] = a[i];
+                    auto it = leftover.find(a[i]);
+                    if (it != leftover.end()) leftover.erase(it);  // absent => invalid witness; the proof will be rejected
+                } else holes.push_back(i);
+            }
+            {
+                auto it = leftover.begin();
+                for (size_t hidx : holes) { if (it == leftover.end()) break; sp[hidx] = it->first; ++it; }
+            }
+            T.lkAp[l].assign(n, Fr::zero()); T.lkSp[l].assign(n, Fr::zero());
+            for (size_t i = 0; i < u; ++i) { T.lkAp[l][i] = a[i]; T.lkSp[l][i] = sp[i]; }
+            for (size_t i = u; i < n; ++i) { T.lkAp[l][i] = rng.fr(); T.lkSp[l][i] = rng.fr(); }
+            tr.write_point(ck.commit_lagrange(T.lkAp[l]));
+            tr.write_point(ck.commit_lagrange(T.lkSp[l]));
         }
-        {
-            auto it = leftover.begin();
-            for (size_t hidx : holes) { if (it == leftover.end()) break; sp[hidx] = it->first; ++it; }
-        }
-        lkAp[l].assign(n, Fr::zero()); lkSp[l].assign(n, Fr::zero());
-        for (size_t i = 0; i < u; ++i) { lkAp[l][i] = a[i]; lkSp[l][i] = sp[i]; }
-        for (size_t i = u; i < n; ++i) { lkAp[l][i] = rng.fr(); lkSp[l][i] = rng.fr(); }
-        tr.write_point(ck.commit_lagrange(lkAp[l]));
-        tr.write_point(ck.commit_lagrange(lkSp[l]));
     }
     Fr beta = tr.squeeze_challenge();
     Fr gamma = tr.squeeze_challenge();
@@ -312,18 +342,19 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
     // permutation grand products
     size_t P = cs.permutation_columns.size(), chunk = c.cs_degree - 2;
     size_t nsets = P == 0 ? 0 : (P + chunk - 1) / chunk;
-    auto perm_col_values = [&](size_t j) -> const std::vector<Fr>& {
-        const Column& col = cs.permutation_columns[j];
-        if (col.is_advice()) return advice[col.index];
-        if (col.type == COL_FIXED) return c.fixed[col.index];
-        return inst[col.index];
-    };
     std::vector<Fr> omega_pow(n); { Fr w = Fr::one(); for (size_t i = 0; i < n; ++i) { omega_pow[i] = w; w *= omega; } }
-    std::vector<std::vector<Fr>> permZ(nsets, std::vector<Fr>(n));
-    {
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        auto perm_col_values = [&](size_t j) -> const std::vector<Fr>& {
+            const Column& col = cs.permutation_columns[j];
+            if (col.is_advice()) return T.advice[col.index];
+            if (col.type == COL_FIXED) return c.fixed[col.index];
+            return T.inst[col.index];
+        };
+        T.permZ.assign(nsets, std::vector<Fr>(n));
         Fr last = Fr::one();
-        for (size_t s = 0; s < nsets; ++s) {
-            size_t lo = s * chunk, hi = std::min(P, lo + chunk);
+        for (size_t s2 = 0; s2 < nsets; ++s2) {
+            size_t lo = s2 * chunk, hi = std::min(P, lo + chunk);
             std::vector<Fr> num(u, Fr::one()), den(u, Fr::one());
             for (size_t j = lo; j < hi; ++j) {
                 const std::vector<Fr>& v = perm_col_values(j);
@@ -334,33 +365,39 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
                 }
             }
             batch_invert(den.data(), den.size());
-            permZ[s][0] = last;
-            for (size_t i = 0; i < u; ++i) permZ[s][i + 1] = permZ[s][i] * num[i] * den[i];
-            last = permZ[s][u];
-            for (size_t i = u + 1; i < n; ++i) permZ[s][i] = rng.fr();
-            tr.write_point(ck.commit_lagrange(permZ[s]));
+            T.permZ[s2][0] = last;
+            for (size_t i = 0; i < u; ++i) T.permZ[s2][i + 1] = T.permZ[s2][i] * num[i] * den[i];
+            last = T.permZ[s2][u];
+            for (size_t i = u + 1; i < n; ++i) T.permZ[s2][i] = rng.fr();
+            tr.write_point(ck.commit_lagrange(T.permZ[s2]));
         }
     }
-    for (size_t l = 0; l < L; ++l) {
-        std::vector<Fr> den(u);
-        for (size_t i = 0; i < u; ++i) den[i] = (lkAp[l][i] + beta) * (lkSp[l][i] + gamma);
-        batch_invert(den.data(), den.size());
-        lkZ[l].assign(n, Fr::zero()); lkZ[l][0] = Fr::one();
-        for (size_t i = 0; i < u; ++i) lkZ[l][i + 1] = lkZ[l][i] * (lkA[l][i] + beta) * (lkS[l][i] + gamma) * den[i];
-        for (size_t i = u + 1; i < n; ++i) lkZ[l][i] = rng.fr();
-        tr.write_point(ck.commit_lagrange(lkZ[l]));
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        for (size_t l = 0; l < L; ++l) {
+            std::vector<Fr> den(u);
+            for (size_t i = 0; i < u; ++i) den[i] = (T.lkAp[l][i] + beta) * (T.lkSp[l][i] + gamma);
+            batch_invert(den.data(), den.size());
+            T.lkZ[l].assign(n, Fr::zero()); T.lkZ[l][0] = Fr::one();
+            for (size_t i = 0; i < u; ++i) T.lkZ[l][i + 1] = T.lkZ[l][i] * (T.lkA[l][i] + beta) * (T.lkS[l][i] + gamma) * den[i];
+            for (size_t i = u + 1; i < n; ++i) T.lkZ[l][i] = rng.fr();
+            tr.write_point(ck.commit_lagrange(T.lkZ[l]));
+        }
     }
-    std::vector<std::vector<Fr>> shA(Sh), shS(Sh), shZ(Sh);
-    for (size_t s = 0; s < Sh; ++s) {
-        shA[s] = compress_rows(cs.shuffles[s].input);
-        shS[s] = compress_rows(cs.shuffles[s].shuffle);
-        std::vector<Fr> den(u);
-        for (size_t i = 0; i < u; ++i) den[i] = shS[s][i] + gamma;
-        batch_invert(den.data(), den.size());
-        shZ[s].assign(n, Fr::zero()); shZ[s][0] = Fr::one();
-        for (size_t i = 0; i < u; ++i) shZ[s][i + 1] = shZ[s][i] * (shA[s][i] + gamma) * den[i];
-        for (size_t i = u + 1; i < n; ++i) shZ[s][i] = rng.fr();
-        tr.write_point(ck.commit_lagrange(shZ[s]));
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        T.shA.resize(Sh); T.shS.resize(Sh); T.shZ.resize(Sh);
+        for (size_t s2 = 0; s2 < Sh; ++s2) {
+            T.shA[s2] = compress_rows(T.row_vars, cs.shuffles[s2].input);
+            T.shS[s2] = compress_rows(T.row_vars, cs.shuffles[s2].shuffle);
+            std::vector<Fr> den(u);
+            for (size_t i = 0; i < u; ++i) den[i] = T.shS[s2][i] + gamma;
+            batch_invert(den.data(), den.size());
+            T.shZ[s2].assign(n, Fr::zero()); T.shZ[s2][0] = Fr::one();
+            for (size_t i = 0; i < u; ++i) T.shZ[s2][i + 1] = T.shZ[s2][i] * (T.shA[s2][i] + gamma) * den[i];
+            for (size_t i = u + 1; i < n; ++i) T.shZ[s2][i] = rng.fr();
+            tr.write_point(ck.commit_lagrange(T.shZ[s2]));
+        }
     }
     // vanishing: random polynomial
     std::vector<Fr> random_poly(n);
@@ -371,19 +408,16 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
     // coefficient forms and extended-coset evaluations
     auto to_coeff = [&](const std::vector<std::vector<Fr>>& cols) { std::vector<std::vector<Fr>> o; for (const auto& v : cols) o.push_back(lagrange_to_coeff(v, k)); return o; };
     auto to_ext = [&](const std::vector<std::vector<Fr>>& cf) { std::vector<std::vector<Fr>> o; for (const auto& v : cf) o.push_back(coeff_to_ext(v, ek)); return o; };
-    std::vector<std::vector<Fr>> adv_c = to_coeff(advice), inst_c = to_coeff(inst), pz_c = to_coeff(permZ);
-    std::vector<std::vector<Fr>> lkAp_c = to_coeff(lkAp), lkSp_c = to_coeff(lkSp), lkZ_c = to_coeff(lkZ), shZ_c = to_coeff(shZ);
-    std::vector<std::vector<Fr>> adv_e = to_ext(adv_c), inst_e = to_ext(inst_c), pz_e = to_ext(pz_c);
-    std::vector<std::vector<Fr>> lkAp_e = to_ext(lkAp_c), lkSp_e = to_ext(lkSp_c), lkZ_e = to_ext(lkZ_c), shZ_e = to_ext(shZ_c);
-    std::vector<VarSrc> ext_vars = make_vars(adv_e, pk.fixed_ext, inst_e);
-    auto perm_col_ext = [&](size_t j) -> const std::vector<Fr>& {
-        const Column& col = cs.permutation_columns[j];
-        if (col.is_advice()) return adv_e[col.index];
-        if (col.type == COL_FIXED) return pk.fixed_ext[col.index];
-        return inst_e[col.index];
-    };
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        T.adv_c = to_coeff(T.advice); T.inst_c = to_coeff(T.inst); T.pz_c = to_coeff(T.permZ);
+        T.lkAp_c = to_coeff(T.lkAp); T.lkSp_c = to_coeff(T.lkSp); T.lkZ_c = to_coeff(T.lkZ); T.shZ_c = to_coeff(T.shZ);
+        T.adv_e = to_ext(T.adv_c); T.inst_e = to_ext(T.inst_c); T.pz_e = to_ext(T.pz_c);
+        T.lkAp_e = to_ext(T.lkAp_c); T.lkSp_e = to_ext(T.lkSp_c); T.lkZ_e = to_ext(T.lkZ_c); T.shZ_e = to_ext(T.shZ_c);
+        T.ext_vars = make_vars(T.adv_e, pk.fixed_ext, T.inst_e);
+    }
 
-    // numerator of h on the coset, folded with y in the verifier's expression order (lib.rs:273-346)
+    // numerator of h on the coset, folded with y in the verifier's expression order (lib.rs:273-346): instance by instance
     std::vector<Fr> hnum(m);
     {
         const Ntt& ne = ntt_ctx(ek);
@@ -394,42 +428,51 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
             auto at = [&](const std::vector<Fr>& e, int64_t rot) -> const Fr& { return e[(i + m + rot * (int64_t)stride) % m]; };
             Fr acc = Fr::zero();
             auto push = [&](const Fr& v) { acc = acc * y + v; };
-            for (const ExprPoly& g : cs.gates) push(eval_expr_at(g, cs.coeff_vals, ext_vars, i, m, stride));
             const Fr &l0 = pk.l0_ext[i], &ll = pk.llast_ext[i], &act = pk.lactive_ext[i];
-            if (nsets > 0) {
-                push(l0 * (Fr::one() - pz_e[0][i]));
-                push(ll * (pz_e[nsets - 1][i].sqr() - pz_e[nsets - 1][i]));
-                for (size_t s = 1; s < nsets; ++s) push(l0 * (pz_e[s][i] - at(pz_e[s - 1], last_rot)));
-                for (size_t s = 0; s < nsets; ++s) {
-                    size_t lo = s * chunk, hi = std::min(P, lo + chunk);
-                    Fr left = at(pz_e[s], 1), right = pz_e[s][i];
-                    for (size_t j = lo; j < hi; ++j) {
-                        const Fr& v = perm_col_ext(j)[i];
-                        left *= v + beta * pk.sigma_ext[j][i] + gamma;
-                        right *= v + beta * delta_pow[j] * pt + gamma;
+            for (size_t q = 0; q < M; ++q) {
+                const InstState& T = S[q];
+                auto perm_col_ext = [&](size_t j) -> const std::vector<Fr>& {
+                    const Column& col = cs.permutation_columns[j];
+                    if (col.is_advice()) return T.adv_e[col.index];
+                    if (col.type == COL_FIXED) return pk.fixed_ext[col.index];
+                    return T.inst_e[col.index];
+                };
+                for (const ExprPoly& g : cs.gates) push(eval_expr_at(g, cs.coeff_vals, T.ext_vars, i, m, stride));
+                if (nsets > 0) {
+                    push(l0 * (Fr::one() - T.pz_e[0][i]));
+                    push(ll * (T.pz_e[nsets - 1][i].sqr() - T.pz_e[nsets - 1][i]));
+                    for (size_t s2 = 1; s2 < nsets; ++s2) push(l0 * (T.pz_e[s2][i] - at(T.pz_e[s2 - 1], last_rot)));
+                    for (size_t s2 = 0; s2 < nsets; ++s2) {
+                        size_t lo = s2 * chunk, hi = std::min(P, lo + chunk);
+                        Fr left = at(T.pz_e[s2], 1), right = T.pz_e[s2][i];
+                        for (size_t j = lo; j < hi; ++j) {
+                            const Fr& v = perm_col_ext(j)[i];
+                            left *= v + beta * pk.sigma_ext[j][i] + gamma;
+                            right *= v + beta * delta_pow[j] * pt + gamma;
+                        }
+                        push((left - right) * act);
                     }
-                    push((left - right) * act);
                 }
-            }
-            for (size_t l = 0; l < L; ++l) {
-                Fr ca = Fr::zero(), ct = Fr::zero();
-                for (const ExprPoly& e : cs.lookups[l].input) ca = ca * theta + eval_expr_at(e, cs.coeff_vals, ext_vars, i, m, stride);
-                for (const ExprPoly& e : cs.lookups[l].table) ct = ct * theta + eval_expr_at(e, cs.coeff_vals, ext_vars, i, m, stride);
-                const Fr &z = lkZ_e[l][i], &ap = lkAp_e[l][i], &sp = lkSp_e[l][i];
-                push(l0 * (Fr::one() - z));
-                push(ll * (z.sqr() - z));
-                push((at(lkZ_e[l], 1) * (ap + beta) * (sp + gamma) - z * (ca + beta) * (ct + gamma)) * act);
-                push(l0 * (ap - sp));
-                push((ap - sp) * (ap - at(lkAp_e[l], -1)) * act);
-            }
-            for (size_t s = 0; s < Sh; ++s) {
-                Fr ca = Fr::zero(), csh = Fr::zero();
-                for (const ExprPoly& e : cs.shuffles[s].input) ca = ca * theta + eval_expr_at(e, cs.coeff_vals, ext_vars, i, m, stride);
-                for (const ExprPoly& e : cs.shuffles[s].shuffle) csh = csh * theta + eval_expr_at(e, cs.coeff_vals, ext_vars, i, m, stride);
-                const Fr& z = shZ_e[s][i];
-                push(l0 * (Fr::one() - z));
-                push(ll * (z.sqr() - z));
-                push((at(shZ_e[s], 1) * (csh + gamma) - z * (ca + gamma)) * act);
+                for (size_t l = 0; l < L; ++l) {
+                    Fr ca = Fr::zero(), ct = Fr::zero();
+                    for (const ExprPoly& e : cs.lookups[l].input) ca = ca * theta + eval_expr_at(e, cs.coeff_vals, T.ext_vars, i, m, stride);
+                    for (const ExprPoly& e : cs.lookups[l].table) ct = ct * theta + eval_expr_at(e, cs.coeff_vals, T.ext_vars, i, m, stride);
+                    const Fr &z = T.lkZ_e[l][i], &ap = T.lkAp_e[l][i], &sp = T.lkSp_e[l][i];
+                    push(l0 * (Fr::one() - z));
+                    push(ll * (z.sqr() - z));
+                    push((at(T.lkZ_e[l], 1) * (ap + beta) * (sp + gamma) - z * (ca + beta) * (ct + gamma)) * act);
+                    push(l0 * (ap - sp));
+                    push((ap - sp) * (ap - at(T.lkAp_e[l], -1)) * act);
+                }
+                for (size_t s2 = 0; s2 < Sh; ++s2) {
+                    Fr ca = Fr::zero(), csh = Fr::zero();
+                    for (const ExprPoly& e : cs.shuffles[s2].input) ca = ca * theta + eval_expr_at(e, cs.coeff_vals, T.ext_vars, i, m, stride);
+                    for (const ExprPoly& e : cs.shuffles[s2].shuffle) csh = csh * theta + eval_expr_at(e, cs.coeff_vals, T.ext_vars, i, m, stride);
+                    const Fr& z = T.shZ_e[s2][i];
+                    push(l0 * (Fr::one() - z));
+                    push(ll * (z.sqr() - z));
+                    push((at(T.shZ_e[s2], 1) * (csh + gamma) - z * (ca + gamma)) * act);
+                }
             }
             hnum[i] = acc;
         }
@@ -453,25 +496,35 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
     // evaluations, in the order lib.rs:220-253 reads them
     auto rot_pt = [&](int64_t r) { return r >= 0 ? x * omega.pow_u64((u64)r) : x * omega_inv.pow_u64((u64)(-r)); };
     std::vector<PolyQuery> queries;  // in the verifier's query order (lib.rs:349-414), built below
-    std::vector<Fr> adv_evals, fix_evals, sig_evals;
-    for (const Query& q : cs.advice_queries) { Fr e = horner(adv_c[q.column.index], rot_pt(q.rotation)); adv_evals.push_back(e); tr.write_scalar(e); }
+    std::vector<Fr> fix_evals, sig_evals;
+    for (size_t q = 0; q < M; ++q)
+        for (const Query& qq : cs.advice_queries) { Fr e = horner(S[q].adv_c[qq.column.index], rot_pt(qq.rotation)); S[q].adv_evals.push_back(e); tr.write_scalar(e); }
     for (const Query& q : cs.fixed_queries) { Fr e = horner(pk.fixed_coeff[q.column.index], rot_pt(q.rotation)); fix_evals.push_back(e); tr.write_scalar(e); }
     Fr random_eval = horner(random_poly, x); tr.write_scalar(random_eval);
     for (size_t j = 0; j < P; ++j) { Fr e = horner(pk.sigma_coeff[j], x); sig_evals.push_back(e); tr.write_scalar(e); }
     Fr x_next = rot_pt(1), x_prev = rot_pt(-1), x_last = rot_pt(-(int64_t)(bf + 1));
-    std::vector<std::array<Fr, 3>> pz_ev(nsets);
-    for (size_t s = 0; s < nsets; ++s) {
-        pz_ev[s][0] = horner(pz_c[s], x); tr.write_scalar(pz_ev[s][0]);
-        pz_ev[s][1] = horner(pz_c[s], x_next); tr.write_scalar(pz_ev[s][1]);
-        if (s + 1 < nsets) { pz_ev[s][2] = horner(pz_c[s], x_last); tr.write_scalar(pz_ev[s][2]); }
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        T.pz_ev.resize(nsets);
+        for (size_t s2 = 0; s2 < nsets; ++s2) {
+            T.pz_ev[s2][0] = horner(T.pz_c[s2], x); tr.write_scalar(T.pz_ev[s2][0]);
+            T.pz_ev[s2][1] = horner(T.pz_c[s2], x_next); tr.write_scalar(T.pz_ev[s2][1]);
+            if (s2 + 1 < nsets) { T.pz_ev[s2][2] = horner(T.pz_c[s2], x_last); tr.write_scalar(T.pz_ev[s2][2]); }
+        }
     }
-    std::vector<std::array<Fr, 5>> lk_ev(L);
-    for (size_t l = 0; l < L; ++l) {
-        lk_ev[l] = {horner(lkZ_c[l], x), horner(lkZ_c[l], x_next), horner(lkAp_c[l], x), horner(lkAp_c[l], x_prev), horner(lkSp_c[l], x)};
-        for (const Fr& e : lk_ev[l]) tr.write_scalar(e);
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        T.lk_ev.resize(L);
+        for (size_t l = 0; l < L; ++l) {
+            T.lk_ev[l] = {horner(T.lkZ_c[l], x), horner(T.lkZ_c[l], x_next), horner(T.lkAp_c[l], x), horner(T.lkAp_c[l], x_prev), horner(T.lkSp_c[l], x)};
+            for (const Fr& e : T.lk_ev[l]) tr.write_scalar(e);
+        }
     }
-    std::vector<std::array<Fr, 2>> sh_ev(Sh);
-    for (size_t s = 0; s < Sh; ++s) { sh_ev[s] = {horner(shZ_c[s], x), horner(shZ_c[s], x_next)}; for (const Fr& e : sh_ev[s]) tr.write_scalar(e); }
+    for (size_t q = 0; q < M; ++q) {
+        InstState& T = S[q];
+        T.sh_ev.resize(Sh);
+        for (size_t s2 = 0; s2 < Sh; ++s2) { T.sh_ev[s2] = {horner(T.shZ_c[s2], x), horner(T.shZ_c[s2], x_next)}; for (const Fr& e : T.sh_ev[s2]) tr.write_scalar(e); }
+    }
 
     // combined quotient polynomial  sum_i xn^i h_i(X)  (vanishing.rs:102-112)
     u64 e4[4] = {n, 0, 0, 0};
@@ -480,14 +533,17 @@ std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, con
     for (size_t i = H; i-- > 0;) for (size_t j = 0; j < n; ++j) h_comb[j] = h_comb[j] * xn + h_pieces[i][j];
     Fr h_eval = horner(h_comb, x);
 
-    for (size_t qi = 0; qi < cs.advice_queries.size(); ++qi) queries.push_back({&adv_c[cs.advice_queries[qi].column.index], rot_pt(cs.advice_queries[qi].rotation), adv_evals[qi]});
-    for (size_t s = 0; s < nsets; ++s) { queries.push_back({&pz_c[s], x, pz_ev[s][0]}); queries.push_back({&pz_c[s], x_next, pz_ev[s][1]}); }
-    for (size_t s = nsets; s-- > 0;) { if (s + 1 == nsets) continue; queries.push_back({&pz_c[s], x_last, pz_ev[s][2]}); }
-    for (size_t l = 0; l < L; ++l) {
-        queries.push_back({&lkZ_c[l], x, lk_ev[l][0]}); queries.push_back({&lkAp_c[l], x, lk_ev[l][2]}); queries.push_back({&lkSp_c[l], x, lk_ev[l][4]});
-        queries.push_back({&lkAp_c[l], x_prev, lk_ev[l][3]}); queries.push_back({&lkZ_c[l], x_next, lk_ev[l][1]});
+    for (size_t q = 0; q < M; ++q) {
+        const InstState& T = S[q];
+        for (size_t qi = 0; qi < cs.advice_queries.size(); ++qi) queries.push_back({&T.adv_c[cs.advice_queries[qi].column.index], rot_pt(cs.advice_queries[qi].rotation), T.adv_evals[qi]});
+        for (size_t s2 = 0; s2 < nsets; ++s2) { queries.push_back({&T.pz_c[s2], x, T.pz_ev[s2][0]}); queries.push_back({&T.pz_c[s2], x_next, T.pz_ev[s2][1]}); }
+        for (size_t s2 = nsets; s2-- > 0;) { if (s2 + 1 == nsets) continue; queries.push_back({&T.pz_c[s2], x_last, T.pz_ev[s2][2]}); }
+        for (size_t l = 0; l < L; ++l) {
+            queries.push_back({&T.lkZ_c[l], x, T.lk_ev[l][0]}); queries.push_back({&T.lkAp_c[l], x, T.lk_ev[l][2]}); queries.push_back({&T.lkSp_c[l], x, T.lk_ev[l][4]});
+            queries.push_back({&T.lkAp_c[l], x_prev, T.lk_ev[l][3]}); queries.push_back({&T.lkZ_c[l], x_next, T.lk_ev[l][1]});
+        }
+        for (size_t s2 = 0; s2 < Sh; ++s2) { queries.push_back({&T.shZ_c[s2], x, T.sh_ev[s2][0]}); queries.push_back({&T.shZ_c[s2], x_next, T.sh_ev[s2][1]}); }
     }
-    for (size_t s = 0; s < Sh; ++s) { queries.push_back({&shZ_c[s], x, sh_ev[s][0]}); queries.push_back({&shZ_c[s], x_next, sh_ev[s][1]}); }
     for (size_t qi = 0; qi < cs.fixed_queries.size(); ++qi) queries.push_back({&pk.fixed_coeff[cs.fixed_queries[qi].column.index], rot_pt(cs.fixed_queries[qi].rotation), fix_evals[qi]});
     for (size_t j = 0; j < P; ++j) queries.push_back({&pk.sigma_coeff[j], x, sig_evals[j]});
     queries.push_back({&h_comb, x, h_eval});

@@ -69,6 +69,9 @@ ProvingKey keygen(const Circuit& c, const CommitKey& ck);
 // multiopen: 0 SHPLONK, 1 GWC; transcript: 0 Blake2b, 1 Keccak256 (the generic parameters of the reference's prover/verifier pair)
 std::vector<uint8_t> create_proof(const ProvingKey& pk, const CommitKey& ck, const std::vector<std::vector<Fr>>& instances,
                                   const WitnessFn& witness, Rng& rng, int multiopen = 0, int transcript = 0);
+// several circuit instances in one transcript (the reference's `instances: &[&[&[Fr]]]`, lib.rs:33-49): instances[m], witnesses[m]
+std::vector<uint8_t> create_proof_multi(const ProvingKey& pk, const CommitKey& ck, const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                        const std::vector<WitnessFn>& witnesses, Rng& rng, int multiopen = 0, int transcript = 0);
 
 // ---- synthetic circuits used by the tests and the bench
 // config 1/2/3: the tests/vector_mul.rs shape — 3 advice, 1 instance, 1 fixed (selector), gate s*(a*b-c),

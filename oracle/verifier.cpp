@@ -147,8 +147,8 @@ Fr eval_expr(const ExprPoly& poly, const std::vector<Fr>& coeffs, const std::vec
 namespace {
 enum CommitKind { K_ADVICE, K_PERM_PRODUCT, K_LOOKUP, K_SHUFFLE, K_FIXED, K_PERM_COMMON, K_H_MSM, K_RANDOM };
 struct CommitRef {
-    int kind, idx;
-    bool operator==(const CommitRef& o) const { return kind == o.kind && idx == o.idx; }  // pointer identity, query.rs:63-74
+    int kind, idx, inst;   // inst: which circuit instance's commitment (advice / permutation product / lookup / shuffle); 0 for VK-wide ones
+    bool operator==(const CommitRef& o) const { return kind == o.kind && idx == o.idx && inst == o.inst; }  // pointer identity, query.rs:63-74
 };
 struct VQuery { CommitRef c; Fr point, eval; };
 
@@ -202,39 +202,44 @@ static void construct_intermediate_sets(const std::vector<VQuery>& queries, std:
 }
 
 // ------------------------------------------------------------------ lib.rs:33-425
-Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
-                   const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace, const char** err_msg, VerifyOptions opts) {
+// `insts` = the reference's `instances: &[&[&[Fr]]]`: one entry per circuit instance sharing this transcript (lib.rs:51-55).
+Error verify_proof_multi(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<std::vector<Fr>>>& insts,
+                         const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace, const char** err_msg, VerifyOptions opts) {
     const ConstraintSystem& cs = vk.cs;
-    if (instances.size() != cs.num_instance_columns) return InvalidInstances;  // lib.rs:51-55
+    for (const auto& instances : insts) if (instances.size() != cs.num_instance_columns) return InvalidInstances;  // lib.rs:51-55
+    const size_t M = insts.size();   // num_proofs (lib.rs:63)
     Domain domain(vk.cs_degree, vk.k);
     TranscriptRead tr(proof, proof_len, opts.transcript);
     bool in_opening = false;
     try {
         tr.common_scalar(vk.transcript_repr);                                   // vk.rs:145-152
-        for (const auto& col : instances) for (const Fr& v : col) tr.common_scalar(v);  // lib.rs:76-82
+        for (const auto& instances : insts) for (const auto& col : instances) for (const Fr& v : col) tr.common_scalar(v);  // lib.rs:76-82
 
-        // lib.rs:86-112
-        std::vector<G1Affine> advice_commitments(cs.num_advice_columns, G1Affine::identity());
+        // lib.rs:86-112: per phase, the advice commitments of EVERY instance, then the phase's challenges
+        std::vector<std::vector<G1Affine>> advice_commitments(M, std::vector<G1Affine>(cs.num_advice_columns, G1Affine::identity()));
         std::vector<Fr> challenges(cs.num_challenges, Fr::zero());
         for (unsigned phase = 0; phase <= cs.max_phase(); ++phase) {
-            for (size_t i = 0; i < cs.num_advice_columns; ++i)
-                if (cs.advice_column_phase[i] == phase) advice_commitments[i] = tr.read_point();
+            for (size_t m = 0; m < M; ++m)
+                for (size_t i = 0; i < cs.num_advice_columns; ++i)
+                    if (cs.advice_column_phase[i] == phase) advice_commitments[m][i] = tr.read_point();
             for (size_t i = 0; i < cs.num_challenges; ++i)
                 if (cs.challenge_phase[i] == phase) challenges[i] = tr.squeeze_challenge();
         }
         Fr theta = tr.squeeze_challenge();                                       // lib.rs:115
         size_t L = cs.lookups.size(), Sh = cs.shuffles.size();
-        std::vector<G1Affine> lk_input(L), lk_table(L), lk_product(L), sh_product(Sh);
-        for (size_t i = 0; i < L; ++i) { lk_input[i] = tr.read_point(); lk_table[i] = tr.read_point(); }  // lookup.rs:82-97
+        std::vector<std::vector<G1Affine>> lk_input(M, std::vector<G1Affine>(L)), lk_table(M, std::vector<G1Affine>(L)), lk_product(M, std::vector<G1Affine>(L)),
+            sh_product(M, std::vector<G1Affine>(Sh));
+        for (size_t m = 0; m < M; ++m)
+            for (size_t i = 0; i < L; ++i) { lk_input[m][i] = tr.read_point(); lk_table[m][i] = tr.read_point(); }  // lib.rs:117-126, lookup.rs:82-97
         Fr beta = tr.squeeze_challenge();
         Fr gamma = tr.squeeze_challenge();
         size_t chunk_len = vk.cs_degree - 2;                                     // permutation.rs:72
         size_t P = cs.permutation_columns.size();
         size_t nsets = P == 0 ? 0 : (P + chunk_len - 1) / chunk_len;
-        std::vector<G1Affine> perm_product(nsets);
-        for (size_t i = 0; i < nsets; ++i) perm_product[i] = tr.read_point();
-        for (size_t i = 0; i < L; ++i) lk_product[i] = tr.read_point();
-        for (size_t i = 0; i < Sh; ++i) sh_product[i] = tr.read_point();
+        std::vector<std::vector<G1Affine>> perm_product(M, std::vector<G1Affine>(nsets));
+        for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < nsets; ++i) perm_product[m][i] = tr.read_point();   // lib.rs:134-139
+        for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < L; ++i) lk_product[m][i] = tr.read_point();         // lib.rs:141-150
+        for (size_t m = 0; m < M; ++m) for (size_t i = 0; i < Sh; ++i) sh_product[m][i] = tr.read_point();        // lib.rs:152-161
         G1Affine random_poly_commitment = tr.read_point();                        // vanishing.rs:49-58
         Fr y = tr.squeeze_challenge();
         size_t H = domain.quotient_poly_degree;
@@ -244,7 +249,7 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
 
         // lib.rs:173-218 instance evaluations
         u64 nexp[4] = {params.n(), 0, 0, 0};
-        std::vector<Fr> instance_evals;
+        std::vector<std::vector<Fr>> instance_evals(M);
         {
             Fr xn = x.pow(nexp);
             int32_t min_rot = 0, max_rot = 0;
@@ -253,41 +258,45 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
                 else if (q.rotation > max_rot) max_rot = q.rotation;
             }
             size_t max_len = 0;
-            for (const auto& col : instances) max_len = std::max(max_len, col.size());
+            for (const auto& instances : insts) for (const auto& col : instances) max_len = std::max(max_len, col.size());
             std::vector<Fr> l_i_s = domain.l_i_range(x, xn, -max_rot, (int32_t)max_len + std::abs(min_rot));
-            for (const Query& q : cs.instance_queries) {
-                const std::vector<Fr>& inst = instances[q.column.index];
-                size_t offset = (size_t)(max_rot - q.rotation);
-                Fr s = Fr::zero();
-                for (size_t i = 0; i < inst.size(); ++i) s += inst[i] * l_i_s[offset + i];
-                instance_evals.push_back(s);
-            }
+            for (size_t m = 0; m < M; ++m)
+                for (const Query& q : cs.instance_queries) {
+                    const std::vector<Fr>& inst = insts[m][q.column.index];
+                    size_t offset = (size_t)(max_rot - q.rotation);
+                    Fr s = Fr::zero();
+                    for (size_t i = 0; i < inst.size(); ++i) s += inst[i] * l_i_s[offset + i];
+                    instance_evals[m].push_back(s);
+                }
         }
 
         // lib.rs:220-253
-        std::vector<Fr> advice_evals(cs.advice_queries.size()), fixed_evals(cs.fixed_queries.size());
-        for (auto& e : advice_evals) e = tr.read_scalar();
+        std::vector<std::vector<Fr>> advice_evals(M, std::vector<Fr>(cs.advice_queries.size()));
+        std::vector<Fr> fixed_evals(cs.fixed_queries.size());
+        for (size_t m = 0; m < M; ++m) for (auto& e : advice_evals[m]) e = tr.read_scalar();
         for (auto& e : fixed_evals) e = tr.read_scalar();
         Fr random_eval = tr.read_scalar();
         std::vector<Fr> perm_common(P);
         for (auto& e : perm_common) e = tr.read_scalar();
         struct PermSet { Fr eval, next_eval, last_eval; bool has_last; };
-        std::vector<PermSet> psets(nsets);
-        for (size_t i = 0; i < nsets; ++i) {                                     // permutation.rs:105-131
-            psets[i].eval = tr.read_scalar();
-            psets[i].next_eval = tr.read_scalar();
-            psets[i].has_last = i + 1 < nsets;
-            if (psets[i].has_last) psets[i].last_eval = tr.read_scalar();
-        }
+        std::vector<std::vector<PermSet>> psets(M, std::vector<PermSet>(nsets));
+        for (size_t m = 0; m < M; ++m)
+            for (size_t i = 0; i < nsets; ++i) {                                 // permutation.rs:105-131
+                psets[m][i].eval = tr.read_scalar();
+                psets[m][i].next_eval = tr.read_scalar();
+                psets[m][i].has_last = i + 1 < nsets;
+                if (psets[m][i].has_last) psets[m][i].last_eval = tr.read_scalar();
+            }
         struct LkEval { Fr product, product_next, input, input_inv, table; };
-        std::vector<LkEval> lk(L);
-        for (auto& e : lk) {                                                     // lookup.rs:127-146
-            e.product = tr.read_scalar(); e.product_next = tr.read_scalar();
-            e.input = tr.read_scalar(); e.input_inv = tr.read_scalar(); e.table = tr.read_scalar();
-        }
+        std::vector<std::vector<LkEval>> lk(M, std::vector<LkEval>(L));
+        for (size_t m = 0; m < M; ++m)
+            for (auto& e : lk[m]) {                                              // lookup.rs:127-146
+                e.product = tr.read_scalar(); e.product_next = tr.read_scalar();
+                e.input = tr.read_scalar(); e.input_inv = tr.read_scalar(); e.table = tr.read_scalar();
+            }
         struct ShEval { Fr product, product_next; };
-        std::vector<ShEval> sh(Sh);
-        for (auto& e : sh) { e.product = tr.read_scalar(); e.product_next = tr.read_scalar(); }
+        std::vector<std::vector<ShEval>> sh(M, std::vector<ShEval>(Sh));
+        for (size_t m = 0; m < M; ++m) for (auto& e : sh[m]) { e.product = tr.read_scalar(); e.product_next = tr.read_scalar(); }
 
         // lib.rs:257-346
         Fr xn = x.pow(nexp);
@@ -297,56 +306,60 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
         Fr l_blind = Fr::zero();
         for (size_t i = 1; i < 1 + bf; ++i) l_blind += l_evals[i];
         Fr l_0 = l_evals[1 + bf];
+        Fr active_rows = Fr::one() - (l_last + l_blind);
 
         std::vector<Fr> exprs;
-        for (const ExprPoly& g : cs.gates) exprs.push_back(eval_expr(g, cs.coeff_vals, advice_evals, fixed_evals, instance_evals, challenges));
-        // permutation.rs:189-288
-        auto column_eval = [&](const Column& c) -> Fr {
-            size_t qi = cs.get_any_query_index(c, 0);
-            if (c.is_advice()) return advice_evals[qi];
-            if (c.type == COL_FIXED) return fixed_evals[qi];
-            return instance_evals[qi];
-        };
-        if (nsets > 0) {
-            exprs.push_back(l_0 * (Fr::one() - psets[0].eval));
-            exprs.push_back((psets[nsets - 1].eval.sqr() - psets[nsets - 1].eval) * l_last);
-            for (size_t i = 1; i < nsets; ++i) exprs.push_back((psets[i].eval - psets[i - 1].last_eval) * l_0);
-            for (size_t ci = 0; ci < nsets; ++ci) {
-                size_t lo = ci * chunk_len, hi = std::min(P, lo + chunk_len);
-                Fr left = psets[ci].next_eval;
-                for (size_t j = lo; j < hi; ++j) left *= column_eval(cs.permutation_columns[j]) + beta * perm_common[j] + gamma;
-                Fr right = psets[ci].eval;
-                Fr current_delta = (beta * x) * fr_consts().delta.pow_u64(ci * chunk_len);
-                for (size_t j = lo; j < hi; ++j) {
-                    right *= column_eval(cs.permutation_columns[j]) + current_delta + gamma;
-                    current_delta *= fr_consts().delta;
+        for (size_t m = 0; m < M; ++m) {   // flat_map over the instances, each: gates, permutation, lookups, shuffles
+            const std::vector<Fr>&adv = advice_evals[m], &ins = instance_evals[m];
+            for (const ExprPoly& g : cs.gates) exprs.push_back(eval_expr(g, cs.coeff_vals, adv, fixed_evals, ins, challenges));
+            // permutation.rs:189-288
+            auto column_eval = [&](const Column& c) -> Fr {
+                size_t qi = cs.get_any_query_index(c, 0);
+                if (c.is_advice()) return adv[qi];
+                if (c.type == COL_FIXED) return fixed_evals[qi];
+                return ins[qi];
+            };
+            const std::vector<PermSet>& ps = psets[m];
+            if (nsets > 0) {
+                exprs.push_back(l_0 * (Fr::one() - ps[0].eval));
+                exprs.push_back((ps[nsets - 1].eval.sqr() - ps[nsets - 1].eval) * l_last);
+                for (size_t i = 1; i < nsets; ++i) exprs.push_back((ps[i].eval - ps[i - 1].last_eval) * l_0);
+                for (size_t ci = 0; ci < nsets; ++ci) {
+                    size_t lo = ci * chunk_len, hi = std::min(P, lo + chunk_len);
+                    Fr left = ps[ci].next_eval;
+                    for (size_t j = lo; j < hi; ++j) left *= column_eval(cs.permutation_columns[j]) + beta * perm_common[j] + gamma;
+                    Fr right = ps[ci].eval;
+                    Fr current_delta = (beta * x) * fr_consts().delta.pow_u64(ci * chunk_len);
+                    for (size_t j = lo; j < hi; ++j) {
+                        right *= column_eval(cs.permutation_columns[j]) + current_delta + gamma;
+                        current_delta *= fr_consts().delta;
+                    }
+                    exprs.push_back((left - right) * (Fr::one() - (l_last + l_blind)));
                 }
-                exprs.push_back((left - right) * (Fr::one() - (l_last + l_blind)));
             }
-        }
-        Fr active_rows = Fr::one() - (l_last + l_blind);
-        auto compress = [&](const std::vector<ExprPoly>& es) {
-            Fr acc2 = Fr::zero();
-            for (const ExprPoly& e : es) acc2 = acc2 * theta + eval_expr(e, cs.coeff_vals, advice_evals, fixed_evals, instance_evals, challenges);
-            return acc2;
-        };
-        for (size_t i = 0; i < L; ++i) {                                          // lookup.rs:159-230
-            const LkEval& e = lk[i];
-            exprs.push_back(l_0 * (Fr::one() - e.product));
-            exprs.push_back(l_last * (e.product.sqr() - e.product));
-            Fr left = e.product_next * (e.input + beta) * (e.table + gamma);
-            Fr right = e.product * (compress(cs.lookups[i].input) + beta) * (compress(cs.lookups[i].table) + gamma);
-            exprs.push_back((left - right) * active_rows);
-            exprs.push_back(l_0 * (e.input - e.table));
-            exprs.push_back((e.input - e.table) * (e.input - e.input_inv) * active_rows);
-        }
-        for (size_t i = 0; i < Sh; ++i) {                                         // shuffle.rs:148-203
-            const ShEval& e = sh[i];
-            exprs.push_back(l_0 * (Fr::one() - e.product));
-            exprs.push_back(l_last * (e.product.sqr() - e.product));
-            Fr left = e.product_next * (compress(cs.shuffles[i].shuffle) + gamma);
-            Fr right = e.product * (compress(cs.shuffles[i].input) + gamma);
-            exprs.push_back((left - right) * active_rows);
+            auto compress = [&](const std::vector<ExprPoly>& es) {
+                Fr acc2 = Fr::zero();
+                for (const ExprPoly& e : es) acc2 = acc2 * theta + eval_expr(e, cs.coeff_vals, adv, fixed_evals, ins, challenges);
+                return acc2;
+            };
+            for (size_t i = 0; i < L; ++i) {                                      // lookup.rs:159-230
+                const LkEval& e = lk[m][i];
+                exprs.push_back(l_0 * (Fr::one() - e.product));
+                exprs.push_back(l_last * (e.product.sqr() - e.product));
+                Fr left = e.product_next * (e.input + beta) * (e.table + gamma);
+                Fr right = e.product * (compress(cs.lookups[i].input) + beta) * (compress(cs.lookups[i].table) + gamma);
+                exprs.push_back((left - right) * active_rows);
+                exprs.push_back(l_0 * (e.input - e.table));
+                exprs.push_back((e.input - e.table) * (e.input - e.input_inv) * active_rows);
+            }
+            for (size_t i = 0; i < Sh; ++i) {                                     // shuffle.rs:148-203
+                const ShEval& e = sh[m][i];
+                exprs.push_back(l_0 * (Fr::one() - e.product));
+                exprs.push_back(l_last * (e.product.sqr() - e.product));
+                Fr left = e.product_next * (compress(cs.shuffles[i].shuffle) + gamma);
+                Fr right = e.product * (compress(cs.shuffles[i].input) + gamma);
+                exprs.push_back((left - right) * active_rows);
+            }
         }
         // vanishing.rs:92-121
         Fr expected_h_eval = Fr::zero();
@@ -360,51 +373,54 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
             h_commitment.append_term(Fr::one(), G1::from_affine(h_commitments[i]));
         }
 
-        // lib.rs:349-414 query list
+        // lib.rs:349-414 query list: per instance advice / permutation / lookups / shuffles, then the VK-wide ones
         std::vector<VQuery> queries;
-        for (size_t qi = 0; qi < cs.advice_queries.size(); ++qi) {
-            const Query& q = cs.advice_queries[qi];
-            queries.push_back({{K_ADVICE, (int)q.column.index}, domain.rotate_omega(x, q.rotation), advice_evals[qi]});
-        }
-        {   // permutation.rs:290-325
-            Fr x_next = domain.rotate_omega(x, 1);
-            Fr x_last = domain.rotate_omega(x, -(int32_t)(bf + 1));
-            for (size_t i = 0; i < nsets; ++i) {
-                queries.push_back({{K_PERM_PRODUCT, (int)i}, x, psets[i].eval});
-                queries.push_back({{K_PERM_PRODUCT, (int)i}, x_next, psets[i].next_eval});
+        for (size_t m = 0; m < M; ++m) {
+            const int im = (int)m;
+            for (size_t qi = 0; qi < cs.advice_queries.size(); ++qi) {
+                const Query& q = cs.advice_queries[qi];
+                queries.push_back({{K_ADVICE, (int)q.column.index, im}, domain.rotate_omega(x, q.rotation), advice_evals[m][qi]});
             }
-            for (size_t i = nsets; i-- > 0;) {
-                if (i + 1 == nsets) continue;  // rev().skip(1)
-                queries.push_back({{K_PERM_PRODUCT, (int)i}, x_last, psets[i].last_eval});
+            {   // permutation.rs:290-325
+                Fr x_next = domain.rotate_omega(x, 1);
+                Fr x_last = domain.rotate_omega(x, -(int32_t)(bf + 1));
+                for (size_t i = 0; i < nsets; ++i) {
+                    queries.push_back({{K_PERM_PRODUCT, (int)i, im}, x, psets[m][i].eval});
+                    queries.push_back({{K_PERM_PRODUCT, (int)i, im}, x_next, psets[m][i].next_eval});
+                }
+                for (size_t i = nsets; i-- > 0;) {
+                    if (i + 1 == nsets) continue;  // rev().skip(1)
+                    queries.push_back({{K_PERM_PRODUCT, (int)i, im}, x_last, psets[m][i].last_eval});
+                }
             }
-        }
-        for (size_t i = 0; i < L; ++i) {                                          // lookup.rs:232-272
-            Fr x_inv = domain.rotate_omega(x, -1), x_next = domain.rotate_omega(x, 1);
-            queries.push_back({{K_LOOKUP, (int)(3 * i + 0)}, x, lk[i].product});
-            queries.push_back({{K_LOOKUP, (int)(3 * i + 1)}, x, lk[i].input});
-            queries.push_back({{K_LOOKUP, (int)(3 * i + 2)}, x, lk[i].table});
-            queries.push_back({{K_LOOKUP, (int)(3 * i + 1)}, x_inv, lk[i].input_inv});
-            queries.push_back({{K_LOOKUP, (int)(3 * i + 0)}, x_next, lk[i].product_next});
-        }
-        for (size_t i = 0; i < Sh; ++i) {                                         // shuffle.rs:205-225
-            Fr x_next = domain.rotate_omega(x, 1);
-            queries.push_back({{K_SHUFFLE, (int)i}, x, sh[i].product});
-            queries.push_back({{K_SHUFFLE, (int)i}, x_next, sh[i].product_next});
+            for (size_t i = 0; i < L; ++i) {                                      // lookup.rs:232-272
+                Fr x_inv = domain.rotate_omega(x, -1), x_next = domain.rotate_omega(x, 1);
+                queries.push_back({{K_LOOKUP, (int)(3 * i + 0), im}, x, lk[m][i].product});
+                queries.push_back({{K_LOOKUP, (int)(3 * i + 1), im}, x, lk[m][i].input});
+                queries.push_back({{K_LOOKUP, (int)(3 * i + 2), im}, x, lk[m][i].table});
+                queries.push_back({{K_LOOKUP, (int)(3 * i + 1), im}, x_inv, lk[m][i].input_inv});
+                queries.push_back({{K_LOOKUP, (int)(3 * i + 0), im}, x_next, lk[m][i].product_next});
+            }
+            for (size_t i = 0; i < Sh; ++i) {                                     // shuffle.rs:205-225
+                Fr x_next = domain.rotate_omega(x, 1);
+                queries.push_back({{K_SHUFFLE, (int)i, im}, x, sh[m][i].product});
+                queries.push_back({{K_SHUFFLE, (int)i, im}, x_next, sh[m][i].product_next});
+            }
         }
         for (size_t qi = 0; qi < cs.fixed_queries.size(); ++qi) {
             const Query& q = cs.fixed_queries[qi];
-            queries.push_back({{K_FIXED, (int)q.column.index}, domain.rotate_omega(x, q.rotation), fixed_evals[qi]});
+            queries.push_back({{K_FIXED, (int)q.column.index, 0}, domain.rotate_omega(x, q.rotation), fixed_evals[qi]});
         }
-        for (size_t i = 0; i < P; ++i) queries.push_back({{K_PERM_COMMON, (int)i}, x, perm_common[i]});  // permutation.rs:328-340
-        queries.push_back({{K_H_MSM, 0}, x, expected_h_eval});                    // vanishing.rs:124-136
-        queries.push_back({{K_RANDOM, 0}, x, random_eval});
+        for (size_t i = 0; i < P; ++i) queries.push_back({{K_PERM_COMMON, (int)i, 0}, x, perm_common[i]});  // permutation.rs:328-340
+        queries.push_back({{K_H_MSM, 0, 0}, x, expected_h_eval});                 // vanishing.rs:124-136
+        queries.push_back({{K_RANDOM, 0, 0}, x, random_eval});
 
         auto base_of = [&](const CommitRef& c) -> G1Affine {
             switch (c.kind) {
-                case K_ADVICE: return advice_commitments[c.idx];
-                case K_PERM_PRODUCT: return perm_product[c.idx];
-                case K_LOOKUP: return (c.idx % 3 == 0) ? lk_product[c.idx / 3] : (c.idx % 3 == 1 ? lk_input[c.idx / 3] : lk_table[c.idx / 3]);
-                case K_SHUFFLE: return sh_product[c.idx];
+                case K_ADVICE: return advice_commitments[c.inst][c.idx];
+                case K_PERM_PRODUCT: return perm_product[c.inst][c.idx];
+                case K_LOOKUP: return (c.idx % 3 == 0) ? lk_product[c.inst][c.idx / 3] : (c.idx % 3 == 1 ? lk_input[c.inst][c.idx / 3] : lk_table[c.inst][c.idx / 3]);
+                case K_SHUFFLE: return sh_product[c.inst][c.idx];
                 case K_FIXED: return vk.fixed_commitments[c.idx];
                 case K_PERM_COMMON: return vk.permutation_commitments[c.idx];
                 default: return random_poly_commitment;
@@ -516,6 +532,12 @@ Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::v
         if (err_msg) *err_msg = e.what;
         return ReferencePanic;
     }
+}
+
+// one circuit instance per transcript: instances.len() == 1, what every caller inside the reference passes
+Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
+                   const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace, const char** err_msg, VerifyOptions opts) {
+    return verify_proof_multi(params, vk, {instances}, proof, proof_len, acc, trace, err_msg, opts);
 }
 
 Error verify_single(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,

@@ -80,8 +80,8 @@ struct VerifyTrace {
     std::vector<Fr> expressions;
 };
 
-// lib.rs:33-425 with V = VerifierSHPLONK, transcript = Blake2bRead, one circuit instance per
-// transcript (instances.len() == 1, as in every reference caller).  Appends this proof's terms
+// lib.rs:33-425, one circuit instance per transcript (instances.len() == 1, as in every reference caller; verify_proof_multi
+// below takes the general `instances: &[&[&[Fr]]]`).  Appends this proof's terms
 // to `acc` exactly as the closure passed to strategy.process does (shplonk.rs:256-264).
 // The generic parameters of verify_proof the reference instantiates (lib.rs:33-40): V in {VerifierSHPLONK, VerifierGWC}
 // (poly/kzg/multiopen/{shplonk,gwc}.rs), T in {Blake2bRead, Keccak256Read} (transcript/mod.rs:104-116).
@@ -91,6 +91,11 @@ struct VerifyOptions { int multiopen = MO_SHPLONK; int transcript = TR_BLAKE2B; 
 Error verify_proof(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,
                    const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace = nullptr,
                    const char** err_msg = nullptr, VerifyOptions opts = VerifyOptions());
+
+// The general form: `insts` is the reference's `instances: &[&[&[Fr]]]`, one entry per circuit instance of the transcript.
+Error verify_proof_multi(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<std::vector<Fr>>>& insts,
+                         const uint8_t* proof, size_t proof_len, DualMSM& acc, VerifyTrace* trace = nullptr,
+                         const char** err_msg = nullptr, VerifyOptions opts = VerifyOptions());
 
 // poly/kzg/strategy.rs:164-176
 Error verify_single(const ParamsKZG& params, const VerifyingKey& vk, const std::vector<std::vector<Fr>>& instances,

@@ -24,6 +24,7 @@ class Setup:
     def __init__(self, L, handle, ninst_cols):
         self.L, self.h, self.ninst_cols = L, handle, ninst_cols
         self.multiopen, self.transcript = SHPLONK, BLAKE2B
+        self.circuit_instances = 1   # instances.len() of verify_proof (lib.rs:33-49); set_circuit_instances()
         buf = ctypes.create_string_buffer(1 << 22)
         n = L.h2o_setup_vk(handle, RAW, buf, len(buf))
         self.vk = buf.raw[:n]
@@ -36,9 +37,16 @@ class Setup:
         self.L.h2o_setup_set_options(self.h, multiopen, transcript)
         return self
 
+    def set_circuit_instances(self, m):
+        """Proofs of this setup carry m circuit instances per transcript: `instances` of every verifier-side helper is then the
+        m x columns list, instance-major."""
+        self.circuit_instances = m
+        return self
+
     def use(self):
         """Select this setup's options for the oracle's verifier entry points (thread-local on the C side)."""
         self.L.h2o_set_verify_options(self.multiopen, self.transcript)
+        self.L.h2o_set_circuit_instances(self.circuit_instances)
 
     def free(self):
         if self.h:
@@ -76,6 +84,35 @@ def prove_vector_mul_len(s, a, b, inst_len, rng_seed=7):
     n = s.L.h2o_prove_vector_mul_len(s.h, ab, bb, inst_len, rng_seed, buf, len(buf), inst)
     assert n > 0
     return buf.raw[:n], [[inst.raw[32 * i:32 * i + 32] for i in range(inst_len)]]
+
+
+def prove_vector_mul_multi(s, m, seed=1, rng_seed=7):
+    """ONE proof over m circuit instances (pseudo-random a, b from `seed`): -> (proof, instances) with instances = m columns,
+    instance-major — the flattened `instances: &[&[&[Fr]]]` the verifier-side helpers take after s.set_circuit_instances(m)"""
+    import random
+    rnd = random.Random(seed)
+    ab = b"".join(le32(rnd.randrange(R_MOD)) for _ in range(m * s.n_mul))
+    bb = b"".join(le32(rnd.randrange(R_MOD)) for _ in range(m * s.n_mul))
+    buf = ctypes.create_string_buffer(1 << 18)
+    inst = ctypes.create_string_buffer(32 * m * s.n_mul)
+    n = s.L.h2o_prove_vector_mul_multi(s.h, m, ab, bb, rng_seed, buf, len(buf), inst)
+    assert n > 0
+    return buf.raw[:n], [[inst.raw[32 * (q * s.n_mul + i):32 * (q * s.n_mul + i + 1)] for i in range(s.n_mul)] for q in range(m)]
+
+
+def prove_shuffle_multi(s, m, data_seed=5, break_at=-1, rng_seed=9):
+    buf = ctypes.create_string_buffer(1 << 18)
+    n = s.L.h2o_prove_shuffle_multi(s.h, m, data_seed, break_at, rng_seed, buf, len(buf))
+    assert n > 0
+    return buf.raw[:n], []
+
+
+def prove_wide_multi(s, m, witness_seed=3, tamper_at=-1, rng_seed=13):
+    buf = ctypes.create_string_buffer(1 << 20)
+    inst = ctypes.create_string_buffer(32 * 8 * m)
+    n = s.L.h2o_prove_wide_multi(s.h, m, witness_seed, tamper_at, rng_seed, buf, len(buf), inst)
+    assert n > 0
+    return buf.raw[:n], [[inst.raw[32 * (8 * q + i):32 * (8 * q + i + 1)] for i in range(8)] for q in range(m)]
 
 
 def prove_vector_mul_batch(s, count, seed=1, threads=8, proof_len=None):
@@ -131,6 +168,7 @@ def _use(s):
         s.use()
     else:
         s.L.h2o_set_verify_options(getattr(s, "multiopen", 0), getattr(s, "transcript", 0))
+        s.L.h2o_set_circuit_instances(1)
 
 
 def oracle_verify_single(s, proof, instances):

@@ -54,6 +54,14 @@ def load():
     L.h2o_prove_vector_mul.argtypes = [c.c_void_p, c.c_char_p, c.c_char_p, c.c_uint64, c.c_char_p, c.c_size_t, c.c_char_p]
     L.h2o_prove_vector_mul_len.restype = c.c_size_t
     L.h2o_prove_vector_mul_len.argtypes = [c.c_void_p, c.c_char_p, c.c_char_p, c.c_size_t, c.c_uint64, c.c_char_p, c.c_size_t, c.c_char_p]
+    L.h2o_set_circuit_instances.argtypes = [c.c_size_t]
+    L.h2o_set_circuit_instances.restype = None
+    L.h2o_prove_vector_mul_multi.restype = c.c_size_t
+    L.h2o_prove_vector_mul_multi.argtypes = [c.c_void_p, c.c_size_t, c.c_char_p, c.c_char_p, c.c_uint64, c.c_char_p, c.c_size_t, c.c_char_p]
+    L.h2o_prove_shuffle_multi.restype = c.c_size_t
+    L.h2o_prove_shuffle_multi.argtypes = [c.c_void_p, c.c_size_t, c.c_uint64, c.c_int, c.c_uint64, c.c_char_p, c.c_size_t]
+    L.h2o_prove_wide_multi.restype = c.c_size_t
+    L.h2o_prove_wide_multi.argtypes = [c.c_void_p, c.c_size_t, c.c_uint64, c.c_int, c.c_uint64, c.c_char_p, c.c_size_t, c.c_char_p]
     L.h2o_prove_vector_mul_batch.restype = c.c_size_t
     L.h2o_prove_vector_mul_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_uint64, c.c_uint, c.c_char_p, c.c_size_t, c.c_char_p]
     L.h2o_prove_shuffle.restype = c.c_size_t
