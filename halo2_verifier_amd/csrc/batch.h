@@ -40,6 +40,7 @@ struct FrvmArgs {
     Fr* shared;
     uint32_t* left_scal;
     const Fr* insteval;   // [query][proof], wide instance vectors only
+    uint32_t* guard_scal; uint32_t n_guard;   // [proof][term][8], guard variant of a GWC plan only (h2v_guard_msm)
 };
 
 // sum_j inst[base + j] * l_{j - rot}(x) for one instance query of every proof (lib.rs:173-218; l_i_range poly/domain.rs:187-212)
@@ -91,6 +92,8 @@ struct h2v_batch {
     unsigned long long* words = nullptr; h2v::Fr* chal = nullptr; h2v::Fr* mult = nullptr; h2v::Fr* slots = nullptr;
     uint32_t* msm_scal = nullptr; h2v::Fr* shared = nullptr; uint32_t* left_scal = nullptr;
     h2v::Fr* insteval = nullptr;  // [query][proof] (wide instance vectors)
+    uint32_t* guard_scal = nullptr;   // [proof][guard term][8] (h2v_guard_msm with GWC)
+    bool want_guard = false;          // the next upload takes the guard variant of the plan
     h2v::G1J* acc = nullptr;      // per group: [2g] left, [2g+1] right
     uint32_t* ok = nullptr;       // [groups]
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;

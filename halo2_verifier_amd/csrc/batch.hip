@@ -19,7 +19,7 @@ template <class T> int dev_alloc(T*& p, size_t count) {
 int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     const Plan& pl = pd->host;
     size_t N = b->max_proofs, G = b->groups;
-    size_t sig = G * 7919u + pl.inst_queries.size() * 31u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
+    size_t sig = pl.guard_term_order.size() * 977u + G * 7919u + pl.inst_queries.size() * 31u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
     if (b->cap_plan_sig == sig && b->pts) return 0;
     int rc;
     uint32_t words = (uint32_t)((pl.stream.size() + 7) / 8);
@@ -39,6 +39,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
     if ((rc = dev_alloc(b->left_scal, N * pl.n_points * 8))) return rc;
     if ((rc = dev_alloc(b->insteval, N * pl.inst_queries.size()))) return rc;
+    if ((rc = dev_alloc(b->guard_scal, N * pl.guard_term_order.size() * 8))) return rc;
     if ((rc = dev_alloc(b->acc, 2 * G))) return rc;
     if ((rc = dev_alloc(b->ok, G))) return rc;
     if ((rc = dev_alloc(b->out_bytes, 128 * G))) return rc;
@@ -80,7 +81,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }  // lib.rs:51-55
     std::vector<size_t> lens(col_lens, col_lens + ncols);
     PlanDevice* pd = nullptr;
-    int rc = ctx_get_plan(ctx, lens, &pd);
+    int rc = ctx_get_plan(ctx, lens, &pd, b->want_guard);
     if (rc) return rc;
     const Plan& pl = pd->host;
     if (proof_len < pl.proof_len) { set_last_error("h2v_batch_upload: proof_len is shorter than this VK's proof"); return H2V_ERR_BAD_ARGUMENT; }
@@ -145,7 +146,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     mark();
     if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
-               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval};
+               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval, b->guard_scal, (uint32_t)pl.guard_term_order.size()};
     if (n && pl.wide_instances) {
         Fr step = pl.omega;
         for (int i = 0; i < 8; ++i) step = step.sqr();   // omega^256: a thread's stride through the column
@@ -276,7 +277,7 @@ int pack_inputs(const Plan& pl, size_t n, const uint8_t* const* proofs, const si
 
 int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t ncols,
                  const size_t* col_lens, const uint8_t* rand32, bool single, int with_pairing, int* per_proof_status, int* batch_ok, uint8_t* out_left,
-                 uint8_t* out_right, h2v_batch** keep) {
+                 uint8_t* out_right, h2v_batch** keep, bool guard = false) {
     if (!ctx || (n && (!proofs || !proof_lens)) || (ncols && !col_lens)) { set_last_error("null argument"); return H2V_ERR_BAD_ARGUMENT; }
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
@@ -296,6 +297,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
         // proofs as one-proof groups of grouped launches, at most MSM_MAX_PROBLEMS / 2 per launch
         const size_t per = MSM_MAX_PROBLEMS / 2;
         if ((rc = scratch_batch_take(ctx, std::min(n ? n : 1, per), pl.n_instance_values, &b))) return rc;
+        b->want_guard = false;
         bool all = true;
         for (size_t off = 0; off < n && !rc; off += per) {
             const size_t m = std::min(per, n - off);
@@ -319,6 +321,7 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
     }
     if ((rc = scratch_batch_take(ctx, n ? n : 1, pl.n_instance_values, &b))) return rc;
     if ((rc = h2v_batch_set_groups(b, 1))) { h2v_batch_destroy(b); return rc; }
+    b->want_guard = guard;
     do {
         if ((rc = upload_impl(b, n, flat.data(), pl.proof_len, iflat.data(), ncols, col_lens, rand32, rand32 ? n : 0))) break;
         if ((rc = launch_impl(b, with_pairing))) break;
@@ -374,7 +377,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
-    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->acc); hipFree(b->ok);
+    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc); hipFree(b->ok);
     hipFree(b->out_bytes); hipFree(b->out_ident); hipFree(b->fold_failed);
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
@@ -561,7 +564,7 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len, const ui
     const uint8_t* pp[1] = {proof}; size_t pl1[1] = {proof_len}; const uint8_t* ip[1] = {instances32};
     int st = 0, ok = 0;
     h2v_batch* b = nullptr;
-    int rc = pack_and_run(ctx, 1, pp, pl1, ip, n_instance_columns, col_lens, one, false, 0, &st, &ok, nullptr, nullptr, &b);
+    int rc = pack_and_run(ctx, 1, pp, pl1, ip, n_instance_columns, col_lens, one, false, 0, &st, &ok, nullptr, nullptr, &b, true);
     if (rc) return rc;
     if (st != 0) { h2v_batch_destroy(b); return st; }
     const Plan& pl = b->plan->host;
@@ -578,6 +581,18 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len, const ui
         if (hipMemcpy(scal.data(), b->msm_scal, scal.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(shared.data(), b->shared, sizeof(Fr) * pl.n_shared, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(pts.data(), b->pts, sizeof(G1A) * pts.size(), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(chal.data(), b->chal, sizeof(Fr) * chal.size(), hipMemcpyDeviceToHost) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
         auto put_pt = [](const G1A& p, uint8_t* o) { if (p.is_identity()) memset(o, 0, 64); else { p.x.to_bytes(o); p.y.to_bytes(o + 32); } };
+        if (!pl.guard_term_order.empty()) {
+            // GWC: term by term as the reference appends them (gwc.rs:86-132), each with its own scalar
+            T = pl.guard_term_order.size();
+            if (T > *n_right) { set_last_error("h2v_guard_msm: output capacity too small"); rc = H2V_ERR_BAD_ARGUMENT; break; }
+            std::vector<uint32_t> gs(T * 8);
+            if (hipMemcpy(gs.data(), b->guard_scal, gs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
+            for (size_t t = 0; t < T; ++t) {
+                auto w = pl.guard_term_order[t];
+                memcpy(right_scalars32 + 32 * t, &gs[t * 8], 32);
+                put_pt(pts[w.first ? pl.n_points + w.second : w.second], right_bases64 + 64 * t);
+            }
+        } else
         for (size_t t = 0; t < T; ++t) {
             auto w = pl.right_term_order[t];
             if (w.first) { shared[w.second].to_bytes(right_scalars32 + 32 * t); put_pt(pts[pl.n_points + w.second], right_bases64 + 64 * t); }

@@ -430,6 +430,13 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
                 for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
             }
+            case OP_STORE_GUARD: {
+                uint32_t raw[8];
+                sf.load(in.a).to_raw(raw);
+                uint32_t* dst = a.guard_scal + ((size_t)p * a.n_guard + in.b) * 8;
+                for (int i = 0; i < 8; ++i) dst[i] = raw[i];
+                break;
+            }
             case OP_STORE_SHARED: {
                 Fr v = sf.load(in.a);
                 if (a.status[p] != 0) v = Fr::zero();

@@ -60,6 +60,7 @@ enum VmOp : uint32_t {
     OP_STORE_SHARED = 14, // shared[proof][b] <- a (Montgomery)
     OP_STORE_LEFT = 15,   // left_scalars[proof][point slot b] <- canonical(a)
     OP_LOAD_INSTEVAL = 16, // d <- instance-query evaluation #a of this proof, computed by k_instance_eval (wide instance vectors)
+    OP_STORE_GUARD = 17,   // guard_scalars[proof][term b] <- canonical(a): one scalar per term of the Guard in reference order (h2v_guard_msm, GWC)
 };
 struct VmInstr { uint32_t op, d, a, b; };
 #define VM_CONST_OPERAND 0x80000000u   // operand a / b of MUL, ADD, SUB: consts[index] instead of a slot
@@ -69,7 +70,7 @@ struct TranscriptSrc {  // one byte of the absorbed stream
     uint8_t kind; uint8_t value; uint32_t offset;
 };
 
-struct PlanOptions { int multiopen = 0; int transcript = 0; int circuit_instances = 1; };  // h2v_options
+struct PlanOptions { int multiopen = 0; int transcript = 0; int circuit_instances = 1; bool guard_terms = false; };  // h2v_options (+ the h2v_guard_msm variant)
 
 struct Plan {
     PlanOptions opts;
@@ -94,6 +95,10 @@ struct Plan {
     std::vector<G1A> shared_bases;
     // reference term order of the right channel (shplonk.rs:256-264): (is_shared, index)
     std::vector<std::pair<uint8_t, uint32_t>> right_term_order;
+    // GWC, guard variant only: the right channel term by term as the reference appends it (gwc.rs:86-132: witness_with_aux, then
+    // commitment_multi query by query, then (eval_multi, -g)) — a commitment opened at several points occurs once per query here,
+    // while the MSM above carries it once with the scalars summed; each term's own scalar is stored by OP_STORE_GUARD
+    std::vector<std::pair<uint8_t, uint32_t>> guard_term_order;
     // instance shape this plan was compiled for
     std::vector<size_t> col_lens;
     uint32_t n_instance_values = 0;
@@ -126,6 +131,6 @@ struct VkDevice {
     std::map<std::vector<size_t>, PlanDevice*> plans;  // keyed by instance column lengths
     std::mutex mu;
 };
-int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice** out);
+int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice** out, bool guard_terms = false);
 
 }  // namespace h2v

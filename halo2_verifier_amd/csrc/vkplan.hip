@@ -200,6 +200,7 @@ struct Builder {
     void store_msm(Val a, uint32_t slot) { push(OP_STORE_MSM, a, 0, slot, false); }
     void store_shared(Val a, uint32_t j) { push(OP_STORE_SHARED, a, 0, j, false); }
     void store_left(Val a, uint32_t slot) { push(OP_STORE_LEFT, a, 0, slot, false); }
+    void store_guard(Val a, uint32_t term) { push(OP_STORE_GUARD, a, 0, term, false); }
 
     // values[i] <- 1 / values[i] for all i with ONE inversion (Montgomery's trick)
     void batch_invert(std::vector<Val>& vals) {
@@ -229,7 +230,7 @@ struct Builder {
         auto n_operands = [&](const Node& nd) -> int {
             switch (nd.op) {
                 case OP_MUL: case OP_ADD: case OP_SUB: return 2;
-                case OP_NEG: case OP_INV: case OP_POW: case OP_SQRN: case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: return 1;
+                case OP_NEG: case OP_INV: case OP_POW: case OP_SQRN: case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: case OP_STORE_GUARD: return 1;
                 default: return 0;
             }
         };
@@ -271,7 +272,7 @@ struct Builder {
                 case OP_MUL: case OP_ADD: case OP_SUB: in.a = operand(nd.op, nd.a); in.b = operand(nd.op, nd.b); break;
                 case OP_NEG: case OP_INV: in.a = slot[nd.a]; break;
                 case OP_POW: case OP_SQRN: in.a = slot[nd.a]; in.b = nd.imm; break;
-                case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: in.a = slot[nd.a]; in.b = nd.imm; break;
+                case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: case OP_STORE_GUARD: in.a = slot[nd.a]; in.b = nd.imm; break;
                 default: in.a = nd.imm; break;  // CONST / LOAD_*
             }
             if (nd.has_result) {
@@ -728,8 +729,15 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         Val power_of_u = b.one();
         std::vector<Val> pu(groups.size());
         for (size_t i = 0; i < groups.size(); ++i) { pu[i] = power_of_u; power_of_u = b.mul(su, power_of_u); }
+        auto guard_term = [&](std::pair<uint8_t, uint32_t> where, Val v) {
+            if (!opts.guard_terms) return;
+            b.store_guard(v, (uint32_t)plan.guard_term_order.size());
+            plan.guard_term_order.push_back(where);
+        };
         for (size_t i = 0; i < groups.size(); ++i) {
-            assign({0, gwc_w_slot[i]}, b.mul(pu[i], point_of[gwc_points[i]]));
+            const Val wz = b.mul(pu[i], point_of[gwc_points[i]]);
+            assign({0, gwc_w_slot[i]}, wz);
+            guard_term({0, gwc_w_slot[i]}, wz);            // witness_with_aux (gwc.rs:118-119, added to the right channel first :127)
             left_scalar[gwc_w_slot[i]] = pu[i];
             plan.left_term_order.push_back({0, gwc_w_slot[i]});
         }
@@ -741,8 +749,8 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
                 if (q->c.kind == K_H_MSM) {
                     std::vector<Val> xnp(H); if (H) xnp[0] = b.one();
                     for (size_t t = 1; t < H; ++t) xnp[t] = b.mul(xnp[t - 1], xn);
-                    for (size_t t = H; t-- > 0;) assign({0, h_slot[t]}, b.mul(w, xnp[t]));
-                } else assign(slot_of(q->c), w);
+                    for (size_t t = H; t-- > 0;) { const Val hw = b.mul(w, xnp[t]); assign({0, h_slot[t]}, hw); guard_term({0, h_slot[t]}, hw); }
+                } else { assign(slot_of(q->c), w); guard_term(slot_of(q->c), w); }   // commitment_multi, query by query (gwc.rs:96-116)
                 eval_batch = b.add(eval_batch, b.mul(power_of_v, q->eval));
                 power_of_v = b.mul(sv, power_of_v);
             }
@@ -750,6 +758,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
         }
         plan.shared_bases.back().y = plan.shared_bases.back().y.neg();  // the last VK-wide base is -g for GWC (gwc.rs:130-131)
         assign({1, (uint32_t)(F + P)}, eval_multi);
+        guard_term({1, (uint32_t)(F + P)}, eval_multi);    // (eval_multi, -g) (gwc.rs:130-131)
     } else {
     Val z_0 = b.one();
     for (int64_t r : rsets[0].rots) z_0 = b.mul(b.sub(su, point_of[r]), z_0);
@@ -869,20 +878,26 @@ void ctx_release_vk(h2v_ctx* ctx) {
     delete ctx->vk;
     ctx->vk = nullptr;
 }
-int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice** out) {
+int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens_in, PlanDevice** out, bool guard_terms) {
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     std::lock_guard<std::mutex> lock(ctx->vk->mu);
-    auto it = ctx->vk->plans.find(col_lens);
+    // the variant h2v_guard_msm runs (per-term Guard scalars; differs from the normal plan only for GWC) is cached under the
+    // column lengths followed by a marker no real length can equal
+    guard_terms = guard_terms && ctx->multiopen == H2V_MULTIOPEN_GWC;
+    std::vector<size_t> key = col_lens_in;
+    if (guard_terms) key.push_back((size_t)-1);
+    const std::vector<size_t>& col_lens = col_lens_in;
+    auto it = ctx->vk->plans.find(key);
     if (it != ctx->vk->plans.end()) { *out = it->second; return 0; }
     PlanDevice* pd = new PlanDevice();
     std::string err;
-    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript; po.circuit_instances = ctx->circuit_instances;
+    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript; po.circuit_instances = ctx->circuit_instances; po.guard_terms = guard_terms;
     int rc = compile_plan(ctx->vk->vk, ctx->params, col_lens, po, pd->host, err);
     if (rc) { set_last_error("plan: " + err); delete pd; return rc; }
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     rc = pd->upload();
     if (rc) { pd->release(); delete pd; return rc; }
-    ctx->vk->plans[col_lens] = pd;
+    ctx->vk->plans[key] = pd;
     *out = pd;
     return 0;
 }

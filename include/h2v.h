@@ -142,8 +142,9 @@ int h2v_verify_each(h2v_ctx* ctx, size_t n,
                     const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens,
                     int* per_proof_status);
 
-/* Debug / parity: the Guard of one proof in reference term order (shplonk.rs:256-264; gwc.rs:126-132, where a
- * commitment opened at several points is reported once, with its scalars summed), and the
+/* Debug / parity: the Guard of one proof term by term in the order the reference appends them (shplonk.rs:256-264;
+ * gwc.rs:86-132: witness_with_aux, commitment_multi query by query — a commitment opened at several points occurs once per
+ * query, each time with that query's own scalar — then (eval_multi, -g)), and the
  * Fiat-Shamir challenges [user challenges.., theta, beta, gamma, y, x, y', v, u] (GWC: [.., x, v, u]).
  * On entry *n_right / *n_left / *n_challenges hold the capacities (in elements). */
 int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len,

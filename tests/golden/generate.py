@@ -26,18 +26,6 @@ import pyref  # noqa: E402
 R = pyref.R
 
 
-def aggregate(terms):
-    """[(scalar, point)] -> the same list with repeated bases merged (first-appearance order, scalars summed mod r).
-    This is how the C ABI reports a GWC Guard (include/h2v.h, h2v_guard_msm)."""
-    order, acc = [], {}
-    for sc, b in terms:
-        key = pyref.g1_xy(b)
-        if key not in acc:
-            order.append(key); acc[key] = 0
-        acc[key] = (acc[key] + sc) % R
-    return [(acc[k], k) for k in order]
-
-
 def case(name, s, proofs, rand_seed, notes):
     params, vk = pyref.read_params_raw(s.params), pyref.read_vk_raw(s.vk)
     mo, trk = s.multiopen, s.transcript
@@ -51,9 +39,9 @@ def case(name, s, proofs, rand_seed, notes):
             g = pyref.guard(params, vk, insts, proof, mo, trk)
             entry["guard_status"] = 0
             entry["challenges"] = [c.to_bytes(32, "little").hex() for c in g["challenges"]]
-            agg = aggregate(g["right"])
-            entry["right_scalars"] = [sc.to_bytes(32, "little").hex() for sc, _ in agg]
-            entry["right_bases"] = [b.hex() for _, b in agg]
+            # the Guard term by term, in the order the reference appends them (shplonk.rs:256-264, gwc.rs:86-132)
+            entry["right_scalars"] = [sc.to_bytes(32, "little").hex() for sc, _ in g["right"]]
+            entry["right_bases"] = [pyref.g1_xy(b).hex() for _, b in g["right"]]
             entry["left_scalars"] = [sc.to_bytes(32, "little").hex() for sc, _ in g["left"]]
             entry["left_bases"] = [pyref.g1_xy(b).hex() for _, b in g["left"]]
             guards.append(g)
