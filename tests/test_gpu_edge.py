@@ -168,6 +168,35 @@ def test_many_public_inputs():
     ctx.close(); s.free()
 
 
+def test_80000_public_inputs_at_k18():
+    """The reference's serialize/examples/vector_mul.rs exposes 2^19 public inputs at k = 21; here 80 000 at k = 18 (the test
+    keygen's limit for a CPU suite).  The instance vector is evaluated by k_instance_eval (one workgroup per proof, Montgomery-trick
+    inversion in chunks), its 2.6 MB are absorbed by the transcript, and everything must equal the oracle bit for bit: challenges,
+    Guard, statuses, accumulators.  The proofs are well-formed byte strings of the right shape (the k = 18 VK has the k = 8
+    circuit's layout) but not proofs of this statement — proving at k = 18 takes minutes — so the verdict is a rejection by the
+    pairing; the accepting case at 5000 inputs is test_many_public_inputs."""
+    import random
+    import halo2_verifier_amd as h2v
+    from circuits import R_MOD
+    s = circuits.setup_vector_mul(18, 80000)
+    s8 = circuits.setup_vector_mul(8, 8)
+    P, _ = circuits.prove_vector_mul_batch(s8, 3, seed=4, threads=3)
+    rnd = random.Random(18)
+    I = [[[circuits.le32(rnd.randrange(R_MOD)) for _ in range(80000)]] for _ in range(3)]
+    ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
+    rc_o, g_o = circuits.oracle_guard(s, P[0], I[0])
+    rc_g, g_g = ctx.guard_msm(P[0], I[0])
+    assert rc_o == rc_g == 0 and g_g == g_o
+    rand = [rnd.randrange(1, R_MOD) for _ in range(3)]
+    got = ctx.verify_batch(P, I, rand)
+    assert got == circuits.oracle_verify_batch(s, P, I, rand) and got[0] is False and got[1] == [0, 0, 0]
+    assert ctx.verify_each(P, I) == [-2, -2, -2]
+    # an instance value that is not a canonical field element cannot be expressed on the reference side: InvalidInstances for that proof
+    I2 = list(I); I2[1] = [I[1][0][:79999] + [b"\xff" * 32]]
+    assert ctx.verify_batch(P, I2, rand)[1] == [0, -1, 0]
+    ctx.close(); s.free(); s8.free()
+
+
 def test_instance_kernel_path_equals_program_path(monkeypatch):
     """Wide instance vectors are evaluated by k_instance_eval instead of being unrolled into the Fr program; the threshold
     (H2V_WIDE_INSTANCES, read when a plan is compiled) is forced to 0 here so that small circuits take the kernel path too:

@@ -170,3 +170,31 @@ def test_config3_shard_size(big):
     b.close()
     assert bad[0] is False and bad[1] == [0] * n
     ctx.close()
+
+
+def test_config2_exactly_1024_proofs_at_k14():
+    """BASELINE.json config 2 as stated: a batch of 1024 distinct proofs at k = 14 on one GPU, bit-exact against the oracle —
+    statuses, both accumulator points and the verdict (the oracle needs ~2 s for the 1024 proofs).  The proofs are the bench's own
+    (bench.load_or_make_proofs: cached under .bench_cache/, generated with the test prover if the cache is missing)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import halo2_verifier_amd as h2v
+    d = bench.load_or_make_proofs(1024, 14, lambda m: None)
+    P = [d["proofs"][1024 * i:1024 * (i + 1)] for i in range(1024)]
+    I = [[[d["inst"][32 * (8 * i + j):32 * (8 * i + j + 1)] for j in range(8)]] for i in range(1024)]
+
+    class S:   # what circuits.oracle_verify_batch needs
+        L = circuits.oracle_lib.load(); params = d["params"]; vk = d["vk"]; ninst_cols = 1; multiopen = 0; transcript = 0
+    assert int.from_bytes(d["params"][:4], "little") == 14
+    ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes))
+    rnd = random.Random(1414)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(1024)]
+    got = ctx.verify_batch(P, I, rand)
+    exp = circuits.oracle_verify_batch(S, P, I, rand)
+    assert got == exp and got[0] is True and got[1] == [0] * 1024
+    # one flipped byte in proof 700's last evaluation: Transcript-clean, rejected by the pairing, same accumulators as the oracle
+    b = bytearray(P[700]); b[900] ^= 1; P2 = list(P); P2[700] = bytes(b)
+    got = ctx.verify_batch(P2, I, rand)
+    assert got == circuits.oracle_verify_batch(S, P2, I, rand) and got[0] is False
+    ctx.close()
