@@ -1,19 +1,37 @@
 //! `extern "C"` binding of include/h2v.h for the halo2_verifier crate (feature "mi355x", needs std + the HIP runtime).
 //! UNCOMPILED in this repository: the build image has no Rust toolchain.  The tested callers of the same ABI are
-//! halo2_verifier_amd/verifier.py and bench.py (ctypes).  See INTEGRATION.md.
+//! halo2_verifier_amd/verifier.py and bench.py (ctypes) and tests/cpp/harness.cpp (C++).  tests/test_cabi_symbols.py checks that
+//! every function include/h2v.h declares is bound here.  See INTEGRATION.md.
 #![allow(non_camel_case_types)]
-use core::ffi::{c_char, c_int, c_void};
+use core::ffi::{c_char, c_float, c_int, c_void};
 
 #[repr(C)] pub struct h2v_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct h2v_batch { _p: [u8; 0] }
-#[repr(C)] pub struct h2v_options { pub multiopen: c_int, pub transcript: c_int }
+/// multiopen: VerifierSHPLONK / VerifierGWC; transcript: Blake2bRead / Keccak256Read; circuit_instances: `instances.len()` of
+/// verify_proof (0 or 1 = one circuit instance per transcript)
+#[repr(C)] pub struct h2v_options { pub multiopen: c_int, pub transcript: c_int, pub circuit_instances: c_int }
 
+pub const H2V_OK: c_int = 0;
+pub const H2V_ERR_INVALID_INSTANCES: c_int = -1;
+pub const H2V_ERR_CONSTRAINT_SYSTEM_FAILURE: c_int = -2;
+pub const H2V_ERR_BOUNDS_FAILURE: c_int = -3;
+pub const H2V_ERR_OPENING: c_int = -4;
+pub const H2V_ERR_TRANSCRIPT: c_int = -5;
+pub const H2V_ERR_INSTANCE_TOO_LARGE: c_int = -6;
+pub const H2V_ERR_REFERENCE_PANIC: c_int = -7;
+pub const H2V_ERR_BAD_ARGUMENT: c_int = -16;
+pub const H2V_ERR_FORMAT: c_int = -17;
+pub const H2V_ERR_DEVICE: c_int = -18;
+pub const H2V_ERR_UNSUPPORTED: c_int = -19;
 pub const H2V_SERDE_PROCESSED: c_int = 0;
 pub const H2V_SERDE_RAW_BYTES: c_int = 1;
+pub const H2V_SERDE_RAW_BYTES_UNCHECKED: c_int = 2;
 pub const H2V_MULTIOPEN_SHPLONK: c_int = 0;
 pub const H2V_MULTIOPEN_GWC: c_int = 1;
 pub const H2V_TRANSCRIPT_BLAKE2B: c_int = 0;
 pub const H2V_TRANSCRIPT_KECCAK256: c_int = 1;
+/// bytes one shard contributes per group to a sharded batch (two Jacobian points + failed-proof count)
+pub const H2V_ACC_RECORD_BYTES: usize = 224;
 
 #[link(name = "h2v_amd")]
 extern "C" {
@@ -31,8 +49,15 @@ extern "C" {
     pub fn h2v_verify_batch(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
                             instances32: *const *const u8, n_instance_columns: usize, col_lens: *const usize, rand32: *const u8,
                             per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+    pub fn h2v_verify_batch_shapes(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
+                                   instances32: *const *const u8, n_instance_columns: usize, col_lens_per_proof: *const usize, rand32: *const u8,
+                                   per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
     pub fn h2v_verify_each(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
                            instances32: *const *const u8, n_instance_columns: usize, col_lens: *const usize, per_proof_status: *mut c_int) -> c_int;
+    pub fn h2v_guard_msm(ctx: *mut h2v_ctx, proof: *const u8, proof_len: usize, instances32: *const u8, n_instance_columns: usize, col_lens: *const usize,
+                         right_scalars32: *mut u8, right_bases64: *mut u8, n_right: *mut usize,
+                         left_scalars32: *mut u8, left_bases64: *mut u8, n_left: *mut usize,
+                         challenges32: *mut u8, n_challenges: *mut usize) -> c_int;
     pub fn h2v_batch_create(ctx: *mut h2v_ctx, max_proofs: usize, max_instance_values_per_proof: usize, out: *mut *mut h2v_batch) -> c_int;
     pub fn h2v_batch_destroy(b: *mut h2v_batch);
     pub fn h2v_batch_upload(b: *mut h2v_batch, n: usize, proofs_flat: *const u8, proof_len: usize, instances_flat: *const u8,
@@ -42,9 +67,13 @@ extern "C" {
     pub fn h2v_batch_set_groups(b: *mut h2v_batch, groups: usize) -> c_int;
     pub fn h2v_batch_finish_groups(b: *mut h2v_batch, per_proof_status: *mut c_int, group_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8,
                                    n_groups: usize) -> c_int;
+    pub fn h2v_batch_accumulators(b: *mut h2v_batch, device_ptr: *mut *mut c_void, nbytes: *mut usize) -> c_int;
+    pub fn h2v_batch_stream(b: *mut h2v_batch) -> *mut c_void;
+    pub fn h2v_batch_set_stream(b: *mut h2v_batch, hip_stream: *mut c_void) -> c_int;
     pub fn h2v_batch_export_accumulators(b: *mut h2v_batch, device_dst: *mut c_void) -> c_int;
     pub fn h2v_batch_fold_check_enqueue(b: *mut h2v_batch, device_accumulators: *const c_void, n_parts: usize) -> c_int;
-    pub fn h2v_batch_set_stream(b: *mut h2v_batch, hip_stream: *mut c_void) -> c_int;
     pub fn h2v_fold_check(ctx: *mut h2v_ctx, device_accumulators: *const c_void, n_parts: usize, ok: *mut c_int,
                           out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+    pub fn h2v_batch_timings(b: *mut h2v_batch, ms: *mut c_float, cap: c_int) -> c_int;
+    pub fn h2v_batch_set_profiling(b: *mut h2v_batch, enabled: c_int) -> c_int;
 }

