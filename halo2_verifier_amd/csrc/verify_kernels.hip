@@ -19,24 +19,55 @@
 
 namespace h2v {
 
+// 32 B in (two 16-byte loads: a point sits at a multiple of 32 bytes inside a proof whose length is a multiple of 32), 72 + 32 B
+// out as 8-byte / 16-byte stores.  Round 1 moved every byte on its own: 13x the algorithmic traffic (profiles/r01_pmc_fetch_write.csv).
 __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
                                                    uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, uint8_t* __restrict__ ycanon,
                                                    int* __restrict__ status) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * np) return;
     uint32_t p = t / np, slot = t % np;
-    const uint8_t* src = proofs + (size_t)p * proof_len + point_offsets[slot];
-    uint8_t enc[32];
-    for (int i = 0; i < 32; ++i) enc[i] = src[i];
-    G1A a;
-    bool ok = g1_decompress(enc, a);
-    // the identity decodes but cannot be absorbed ("cannot write points at infinity to the transcript")
-    if (!ok || a.is_identity()) { status_set(status, p, slot < n_main_points ? H2V_DEV_ST_TRANSCRIPT : H2V_DEV_ST_OPENING); a = G1A::identity(); }
-    pts[(size_t)p * np + slot] = a;
-    uint8_t yb[32];
-    a.y.to_bytes(yb);
-    uint8_t* dst = ycanon + ((size_t)p * np + slot) * 32;
-    for (int i = 0; i < 32; ++i) dst[i] = yb[i];
+    const uint4* src = reinterpret_cast<const uint4*>(proofs + (size_t)p * proof_len + point_offsets[slot]);
+    const uint4 lo = src[0], hi = src[1];
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    // G1Affine::from_bytes (compressed): flags in the top byte, x below
+    const bool is_inf = (w[7] >> 24) & G1_FLAG_IDENTITY, sign = (w[7] >> 24) & G1_FLAG_SIGN;
+    w[7] &= 0x3fffffffu;
+    G1A a = G1A::identity();
+    bool ok = !Fq::geq_p(w);
+    uint32_t yraw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) {
+        const Fq x = Fq::from_raw(w);
+        if (is_inf) ok = false;   // the identity decodes (x = 0, no sign) but cannot be absorbed ("cannot write points at infinity to the transcript"): an error either way
+        else {
+            const Fq three = {{FqParams::ONE(0), FqParams::ONE(1), FqParams::ONE(2), FqParams::ONE(3), FqParams::ONE(4), FqParams::ONE(5), FqParams::ONE(6), FqParams::ONE(7), FqParams::ONE(8)}};
+            const Fq rhs = x.sqr() * x + (three + three + three);
+            Fq y = fq_sqrt_candidate(rhs);
+            if (y.sqr() != rhs) ok = false;
+            else {
+                y.to_raw(yraw);                       // canonical y: its parity decides the sign, its bytes are absorbed
+                uint32_t nz = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) nz |= yraw[i];
+                if ((bool)(yraw[0] & 1u) != sign && nz) {   // the other root: p - y (y = 0 is its own negative)
+                    y = y.neg();
+                    uint64_t borrow = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const uint64_t d = (uint64_t)FqParams::P(i) - yraw[i] - borrow; yraw[i] = (uint32_t)d; borrow = (d >> 32) & 1u; }
+                }
+                a.x = x; a.y = y;
+            }
+        }
+    }
+    if (!ok) { status_set(status, p, slot < n_main_points ? H2V_DEV_ST_TRANSCRIPT : H2V_DEV_ST_OPENING); a = G1A::identity(); for (int i = 0; i < 8; ++i) yraw[i] = 0; }
+    // 72-byte point: nine 8-byte stores (72 p is always 8-byte aligned)
+    uint2* dp = reinterpret_cast<uint2*>(pts + ((size_t)p * np + slot));
+    const uint32_t* av = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dp[i] = make_uint2(av[2 * i], av[2 * i + 1]);
+    uint4* dy = reinterpret_cast<uint4*>(ycanon + ((size_t)p * np + slot) * 32);
+    dy[0] = make_uint4(yraw[0], yraw[1], yraw[2], yraw[3]);
+    dy[1] = make_uint4(yraw[4], yraw[5], yraw[6], yraw[7]);
 }
 
 __global__ void __launch_bounds__(256) k_check_scalars(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ scalar_offsets,
