@@ -46,6 +46,8 @@ def hw_queue_env():
         v = int(os.environ.get("GPU_MAX_HW_QUEUES", MAX_HW_QUEUES))
     except ValueError:
         v = MAX_HW_QUEUES
+    if os.environ.get("H2V_BENCH_RAW_HW_QUEUES") == "1":   # diagnosis only: take the inherited value as it is
+        return
     os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(v, MAX_HW_QUEUES)))
 
 

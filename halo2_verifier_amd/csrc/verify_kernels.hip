@@ -566,9 +566,12 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     if (!a.n) return 0;
     // LDS for the hottest slots: 2304 bytes per slot and wave.  Every wave should still get a CU of its own (a program is a
     // latency chain, and a second wave on the CU slows both), so the budget follows the number of waves: the whole 160 KB of a
-    // CU while there are at most 256 waves, half of it up to 512, a third beyond.
+    // CU while there are at most 256 waves, half of it up to 384.
     const uint32_t waves = (a.n + 63) / 64;
-    const uint32_t budget = waves <= 256 ? 156 * 1024 : (waves <= 512 ? 78 * 1024 : 52 * 1024);
+    // (a launch with more waves than that is a throughput launch — several of them are in flight — and an LDS-hungry kernel keeps
+    // the other kernels' workgroups off its CUs: a small slice then)
+    uint32_t budget = waves <= 256 ? 156 * 1024 : (waves <= 384 ? 78 * 1024 : 36 * 1024);
+    if (const char* e = getenv("H2V_FRVM_LDS_KB")) budget = (uint32_t)atoi(e) * 1024;   // tuning knob
     const uint32_t lds_slots = std::min<uint32_t>(n_slots, budget / (H2V_LIMBS * 64 * 4));
     const size_t lds = (size_t)lds_slots * H2V_LIMBS * 64 * 4;
     static std::atomic<size_t> granted{0};   // raising the limit is per function and sticky; do it once per size class

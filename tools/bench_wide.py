@@ -3,7 +3,7 @@
 lookups, degree 5) and the other multi-open / transcript instantiations on the headline VK (--circuit vector_mul):
 batches of `--batch` proofs, `--groups` batches per launch, `--depth` launches in flight.  Not the headline bench (bench.py); numbers quoted in DESIGN.md."""
 import argparse, os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ["GPU_MAX_HW_QUEUES"] = str(min(16, int(os.environ.get("GPU_MAX_HW_QUEUES", "16") or 16)))   # clamped: see bench.py hw_queue_env()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import circuits
