@@ -198,3 +198,44 @@ def test_config2_exactly_1024_proofs_at_k14():
     got = ctx.verify_batch(P2, I, rand)
     assert got == circuits.oracle_verify_batch(S, P2, I, rand) and got[0] is False
     ctx.close()
+
+
+def test_rccl_backend_single_rank_smoke(big):
+    """The collective call the N > 1 bench issues — init_process_group("nccl") (= RCCL) with a device id, all_gather_into_tensor of
+    uint8 accumulator records on a side stream, fold + pairing enqueued behind it — with a world of ONE rank: the only RCCL run
+    this one-GPU pool allows (RCCL refuses two ranks on one device).  It pins the dtype / stream / API usage, not the exchange."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import halo2_verifier_amd as h2v
+    from halo2_verifier_amd import distributed as h2d
+    s, P, I = big
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ctx = _ctx(s)
+        n, G = 32, 2
+        rnd = random.Random(8)
+        rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+        stream = torch.cuda.Stream()
+        b = h2v.Batch(ctx, n, 8, stream=stream.cuda_stream, groups=G)
+        flat = b"".join(P[:n]); inst = b"".join(b"".join(col) for i in I[:n] for col in i)
+        b.upload(flat, 1024, inst, [8], b"".join(r.to_bytes(32, "little") for r in rand))
+        local = torch.empty(h2d.ACC_BYTES * G, dtype=torch.uint8, device="cuda:0")
+        with torch.cuda.stream(stream):
+            b.launch(with_pairing=False)
+            b.export_accumulators(local.data_ptr())
+            out = torch.empty_like(local)
+            dist.all_gather_into_tensor(out, local)          # what gather_accumulators does for world_size > 1
+            b.fold_check_enqueue(out.data_ptr(), 1)
+        ok, st, left, right = b.finish_groups()
+        dist.barrier(device_ids=[0])
+        assert ok == [True, True] and st == [0] * n
+        for g in range(G):
+            ref = ctx.verify_batch(P[g * 16:(g + 1) * 16], I[g * 16:(g + 1) * 16], rand[g * 16:(g + 1) * 16])
+            assert (left[g], right[g]) == (ref[2], ref[3]) and ref[0]
+        b.close(); ctx.close()
+    finally:
+        dist.destroy_process_group()
