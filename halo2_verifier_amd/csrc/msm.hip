@@ -61,14 +61,17 @@ __host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E) {
 #define MSM_HEAVY_THREADS 256
 
 // lanes that share a window's bucket reduction: one wave up to 2048 buckets, four beyond.  A window's reduction is a dependent
-// chain of 2 * slice + ~c + log2(T) group additions on every lane, so when the launch has few (problem, window) pairs — the
-// latency-bound case: one 20-step launch is 480 of them on 256 CUs — more lanes per window shorten the chain for free: four waves
-// while every workgroup still gets a CU of its own (108 KB of LDS each), two waves while two fit per CU.
+// chain of 2 * slice + ~c + log2(T) group additions on every lane (phases of one wave in the 20-step launch, by s_memtime: running
+// sums 296 us, slice weighting 95 us, butterfly 56 us), so more lanes per window shorten the chain — but only while the launch has
+// few workgroups.  Measured (gpurun_out/r02_winT*, r02_win4): 1 / 2 / 4 waves per window take 0.47 / 0.35 / 0.31 ms at 192
+// workgroups, but 0.48 / 0.59 / 0.60 ms at 480; splitting each of the 480 windows between two ONE-wave workgroups (the later one
+// adding the halves) also loses, 0.59 ms; so does a compact group law with out-of-line field products (0.65 ms) — the per-operation
+// cost of this kernel rises with the number of its waves per CU, whatever their grouping.  Hence: four waves per window up to
+// 256 workgroups, one wave beyond.
 static inline uint32_t msm_window_threads(uint32_t buckets, uint32_t n_workgroups = 0xffffffffu) {
     if (buckets <= 64) return std::max(1u, buckets);
     if (n_workgroups != 0xffffffffu) { static const char* e = getenv("H2V_MSM_WIN_T"); if (e) return (uint32_t)atoi(e); }   // tuning knob
     if (buckets > 2048 || (buckets >= 256 && n_workgroups <= 256)) return 256u;
-    if (buckets >= 128 && n_workgroups <= 512) return 128u;
     return 64u;
 }
 
