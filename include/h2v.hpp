@@ -53,7 +53,8 @@ inline void check(int rc) { if (rc != 0) throw Failure(rc, h2v_last_error()); }
 
 typedef std::vector<uint8_t> Bytes;
 typedef std::vector<Bytes> Column;            // one instance column: 32-byte little-endian canonical Fr values
-typedef std::vector<Column> Instances;        // one circuit instance: its columns (the reference's &[&[Fr]])
+typedef std::vector<Column> Instances;        // one circuit instance: its columns (the reference's &[&[Fr]]); with circuit_instances = M
+                                              // (lib.rs:43: instances.len()) the M x columns of the transcript's instances, instance by instance
 
 struct ParamsKZG { Bytes bytes; SerdeFormat format = SerdeFormat::RawBytes; };
 struct VerifyingKey { Bytes bytes; SerdeFormat format = SerdeFormat::RawBytes; };
@@ -61,8 +62,9 @@ struct VerifyingKey { Bytes bytes; SerdeFormat format = SerdeFormat::RawBytes; }
 // ParamsKZG + VerifyingKey resident on one GPU (h2v_ctx)
 class Context {
 public:
-    Context(const ParamsKZG& p, const VerifyingKey& vk, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b) {
-        h2v_options o{(int)mo, (int)tr, 1};
+    Context(const ParamsKZG& p, const VerifyingKey& vk, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b,
+            int circuit_instances = 1) {
+        h2v_options o{(int)mo, (int)tr, circuit_instances};
         check(h2v_ctx_create_ex(p.bytes.data(), p.bytes.size(), (int)p.format, vk.bytes.data(), vk.bytes.size(), (int)vk.format, device, &o, &h_));
     }
     ~Context() { if (h_) h2v_ctx_destroy(h_); }
@@ -78,7 +80,8 @@ namespace detail {
 // pointer-array view of (proof, instances) pairs in the layout h2v_verify_batch / h2v_verify_each take
 struct Packed {
     std::vector<const uint8_t*> proofs, insts;
-    std::vector<size_t> lens, col_lens;
+    std::vector<size_t> lens, col_lens, col_lens_per_proof;   // col_lens: proof 0's shape; per proof: [n][cols]
+    bool uniform = true;                                        // every proof has proof 0's instance shape
     std::vector<Bytes> flat;
     Packed(const std::vector<std::pair<Instances, Bytes>>& items, size_t ncols_if_empty) {
         for (const auto& it : items) {
@@ -93,8 +96,10 @@ struct Packed {
         else col_lens.assign(ncols_if_empty, 0);
         for (const auto& it : items) {
             if (it.first.size() != col_lens.size()) throw Failure(H2V_ERR_INVALID_INSTANCES, "instances do not match the VK's instance column count");
-            for (size_t c = 0; c < col_lens.size(); ++c)
-                if (it.first[c].size() != col_lens[c]) throw Failure(H2V_ERR_BAD_ARGUMENT, "all proofs of one batch share one instance shape");
+            for (size_t c = 0; c < col_lens.size(); ++c) {
+                if (it.first[c].size() != col_lens[c]) uniform = false;      // verify_proof takes `instances` per call: shapes may differ
+                col_lens_per_proof.push_back(it.first[c].size());
+            }
         }
     }
 };
@@ -104,8 +109,9 @@ struct Packed {
 // Here the proofs are queued on the host and the whole batch runs on the GPU at finalize().
 class AccumulatorStrategy {
 public:
-    explicit AccumulatorStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b)
-        : params_(p), device_(device), mo_(mo), tr_(tr) {}
+    explicit AccumulatorStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b,
+                                 int circuit_instances = 1)
+        : params_(p), device_(device), mo_(mo), tr_(tr), ci_(circuit_instances) {}
     // rand32: the Fr::random draws of process() (kzg/strategy.rs:129), one 32-byte canonical scalar per proof; empty = OS RNG
     void set_randomness(Bytes rand32) { rand_ = std::move(rand32); }
     void push(const VerifyingKey& vk, Instances inst, Bytes proof) {
@@ -115,15 +121,19 @@ public:
     }
     // -> true iff every verify_proof succeeded and the pairing check passed; statuses() then holds the per-proof plonk::Error
     bool finalize() {
-        Context ctx(params_, vk_, device_, mo_, tr_);
+        Context ctx(params_, vk_, device_, mo_, tr_, ci_);
         size_t ncols = 0;
         check(h2v_ctx_proof_shape(ctx.handle(), nullptr, nullptr, nullptr, nullptr, &ncols));
         detail::Packed pk(items_, ncols);
         statuses_.assign(items_.size() ? items_.size() : 1, 0);
         int ok = 0;
         if (!rand_.empty() && rand_.size() != 32 * items_.size()) throw Failure(H2V_ERR_BAD_ARGUMENT, "one 32-byte draw per proof");
-        check(h2v_verify_batch(ctx.handle(), items_.size(), pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens.data(),
-                               rand_.empty() ? nullptr : rand_.data(), statuses_.data(), &ok, left_, right_));
+        if (pk.uniform)
+            check(h2v_verify_batch(ctx.handle(), items_.size(), pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens.data(),
+                                   rand_.empty() ? nullptr : rand_.data(), statuses_.data(), &ok, left_, right_));
+        else
+            check(h2v_verify_batch_shapes(ctx.handle(), items_.size(), pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens_per_proof.data(),
+                                          rand_.empty() ? nullptr : rand_.data(), statuses_.data(), &ok, left_, right_));
         statuses_.resize(items_.size());
         return ok != 0;
     }
@@ -132,7 +142,7 @@ public:
     const uint8_t* right() const { return right_; }
 
 private:
-    ParamsKZG params_; VerifyingKey vk_; int device_; MultiOpen mo_; TranscriptKind tr_;
+    ParamsKZG params_; VerifyingKey vk_; int device_; MultiOpen mo_; TranscriptKind tr_; int ci_;
     std::vector<std::pair<Instances, Bytes>> items_;
     Bytes rand_;
     std::vector<int> statuses_;
@@ -142,10 +152,11 @@ private:
 // kzg/strategy.rs:143-181: one pairing per proof, checked inside verify_proof
 class SingleStrategy {
 public:
-    explicit SingleStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b)
-        : params_(p), device_(device), mo_(mo), tr_(tr) {}
+    explicit SingleStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b,
+                            int circuit_instances = 1)
+        : params_(p), device_(device), mo_(mo), tr_(tr), ci_(circuit_instances) {}
     Error verify(const VerifyingKey& vk, const Instances& inst, const Bytes& proof) const {
-        Context ctx(params_, vk, device_, mo_, tr_);
+        Context ctx(params_, vk, device_, mo_, tr_, ci_);
         std::vector<std::pair<Instances, Bytes>> one{{inst, proof}};
         size_t ncols = 0;
         check(h2v_ctx_proof_shape(ctx.handle(), nullptr, nullptr, nullptr, nullptr, &ncols));
@@ -157,7 +168,7 @@ public:
     }
 
 private:
-    ParamsKZG params_; int device_; MultiOpen mo_; TranscriptKind tr_;
+    ParamsKZG params_; int device_; MultiOpen mo_; TranscriptKind tr_; int ci_;
 };
 
 // lib.rs:33-49.  SingleStrategy: returns the proof's plonk::Error (Ok = accepted).
