@@ -50,6 +50,7 @@ struct MsmProblem {
     uint32_t sstride, bstride, n;
     uint32_t n1;
     const uint32_t* scalars2; const G1A* bases2;
+    uint32_t glv_off = 0;   // first record of this problem in the launch's GLV table (set by msm_enqueue_multi)
     MsmProblem() : scalars(nullptr), bases(nullptr), out(nullptr), sstride(8), bstride(1), n(0), n1(0), scalars2(nullptr), bases2(nullptr) {}
     MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n_) : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n_), n1(n_), scalars2(nullptr), bases2(nullptr) {}
     MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n1_, const uint32_t* s2, const G1A* b2, uint32_t n2)
@@ -79,6 +80,9 @@ struct MsmWorkspace {
     MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
+    uint32_t* glv = nullptr;         // [cap_list / 2] signed window digits of the launch's terms, window-major per problem (LDS sort path)
+    uint32_t* seg_total = nullptr;   // [problems * windows] entries per list segment
+    uint32_t* seg_start = nullptr;   // [problems * windows + 1] logical start of every segment
     size_t cap_buckets = 0, cap_list = 0;
     // optional HIP events around msm_accumulate (the dominant kernel: bench.py's roofline.kernels), recorded when `profile` is set
     bool profile = false, profile_recorded = false;

@@ -47,6 +47,8 @@ namespace h2v {
 // kernel holds 2 waves per SIMD (131072 lanes per round), and with a fixed chunk of 32 a 20-step launch (6.4 M entries) needed
 // 1.5 rounds — the second one half empty, i.e. the time of 64 additions per SIMD slot for 49 additions' worth of work.  The chunk
 // is the smallest length that fits E into a whole number of rounds (k rounds of at most 64 entries per lane), at least 16.
+#define MSM_LDS_SORT_MAX_TERMS 16384u
+#define MSM_SORT_THREADS 512u
 #define MSM_CHUNK_MIN 16u
 #define MSM_CHUNK_MAX 64u
 #define MSM_ACC_LANES_PER_ROUND 131072u
@@ -125,6 +127,9 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&glv, (cap_list / 2 + 1) * 4));   // digit table: one word per (term, window)
+    H2V_HIP_CHECK(hipMalloc(&seg_total, ((size_t)128 * max_problems + 2) * 4));
+    H2V_HIP_CHECK(hipMalloc(&seg_start, ((size_t)128 * max_problems + 2) * 4));
     for (int i = 0; i < 2; ++i) if (!ev_acc[i]) H2V_HIP_CHECK(hipEventCreate(&ev_acc[i]));
     return 0;
 }
@@ -138,6 +143,10 @@ void MsmWorkspace::release() {
     if (problems) hipFree(problems);
     if (block_sums) hipFree(block_sums);
     if (partial) hipFree(partial);
+    if (glv) hipFree(glv);
+    if (seg_total) hipFree(seg_total);
+    if (seg_start) hipFree(seg_start);
+    glv = seg_total = seg_start = nullptr;
     counts = offsets = cursor = list = block_sums = nullptr; bucket_pts = window_sums = partial = nullptr; problems = nullptr;
     for (int i = 0; i < 2; ++i) if (ev_acc[i]) { hipEventDestroy(ev_acc[i]); ev_acc[i] = nullptr; }
     cap_terms = 0; cap_problems = 0; profile_recorded = false;
@@ -291,6 +300,135 @@ __global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const M
     }
 }
 
+// ---- LDS counting sort (round 2).  The global counting sort above stores every 4-byte list entry at a position of its own: each
+// store costs a 32-byte sector (0.4 GB of write traffic for 41 MB of list), and it needs two passes over the scalars, a three-kernel
+// prefix sum and one global atomic per (tile, bin).  When a problem is small enough for ONE window's entries to fit LDS as 16-bit
+// records (at most 16 384 terms: every batch up to 1365 proofs of the toy VK), the sort runs per (problem, window) inside one workgroup:
+//   msm_glv_prep   one lane per term: GLV halves and, from them, the signed c-bit digits of EVERY window, one word per (window, term),
+//                  window-major; a term whose scalar is zero or whose base is the identity gets all-zero words and is skipped
+//   msm_sort_lds   one workgroup per (problem, window): histogram of the window's signed digits in LDS, exclusive scan, scatter into
+//                  an LDS list of 16-bit records, then ONE contiguous store of the window's list segment and of its bin table
+//   msm_seg_scan   logical start of every segment (a 480-entry prefix sum for the 20-step launch) and the entry total
+// digit table: for problem q (first word dig_off = glv_off * windows), window w, term t: word [dig_off + w * n + t] holds the two
+// signed digits of the term's GLV halves, 16 bits each: magnitude (0 = no entry) | 0x8000 when the ENTRY is negated (digit sign xor
+// the half's sign).  Written window-major so that the sort of window w reads n consecutive words.
+__global__ void __launch_bounds__(256) msm_glv_prep(const MsmProblem* __restrict__ prs, uint32_t n_problems, MsmPlan p, uint32_t* __restrict__ dig) {
+    const uint32_t q = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_problems) return;
+    const MsmProblem pq = prs[q];
+    if (t >= pq.n) return;
+    uint32_t* out = dig + (size_t)pq.glv_off * p.windows + t;
+    const uint32_t* sc = t < pq.n1 ? pq.scalars + (size_t)pq.sstride * t : pq.scalars2 + (size_t)pq.sstride * (t - pq.n1);
+    uint32_t nz = 0;
+    for (int i = 0; i < 8; ++i) nz |= sc[i];
+    if (nz) {   // identity bases contribute nothing
+        const uint32_t* bw = reinterpret_cast<const uint32_t*>(t < pq.n1 ? pq.bases + (size_t)pq.bstride * t : pq.bases2 + (size_t)pq.bstride * (t - pq.n1));
+        uint32_t any = 0;
+        for (int i = 0; i < (int)(sizeof(G1A) / 4); ++i) any |= bw[i];
+        nz = any;
+    }
+    if (!nz) { for (uint32_t w = 0; w < p.windows; ++w) out[(size_t)w * pq.n] = 0; return; }
+    GlvHalf h[2];
+    glv_decompose(sc, h[0], h[1]);
+    const uint32_t half_range = 1u << (p.c - 1);
+    uint32_t carry[2] = {0, 0};
+    for (uint32_t w = 0; w < p.windows; ++w) {
+        uint32_t word = 0;
+#pragma unroll
+        for (uint32_t hf = 0; hf < 2; ++hf) {
+            const uint32_t raw = raw_window(h[hf].mag, w, p.c) + carry[hf];
+            const bool neg_digit = raw > half_range;       // digit = raw - 2^c, carry into the next window
+            const uint32_t mag = neg_digit ? (1u << p.c) - raw : raw;
+            carry[hf] = neg_digit ? 1u : 0u;
+            const uint32_t d16 = mag ? (mag | ((neg_digit != h[hf].neg) ? 0x8000u : 0u)) : 0u;
+            word |= d16 << (16 * hf);
+        }
+        out[(size_t)w * pq.n] = word;
+    }
+}
+__global__ void __launch_bounds__(MSM_SORT_THREADS) msm_sort_lds(const MsmProblem* __restrict__ prs, const uint32_t* __restrict__ dig, MsmPlan p, uint32_t stride,
+                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ list,
+                                                                 uint32_t* __restrict__ seg_total) {
+    extern __shared__ uint32_t sort_lds[];            // hist[buckets] | scan scratch[MSM_SORT_THREADS] | 16-bit records[2 n]
+    uint32_t* hist = sort_lds;
+    uint32_t* part = sort_lds + p.buckets;
+    unsigned short* rec = reinterpret_cast<unsigned short*>(part + MSM_SORT_THREADS);
+    const uint32_t w = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const MsmProblem pq = prs[q];
+    const uint32_t n = pq.n, seg = q * p.windows + w;
+    const uint32_t* dw = dig + (size_t)pq.glv_off * p.windows + (size_t)w * n;    // this window's digits, one word per term
+    for (uint32_t i = tid; i < p.buckets; i += MSM_SORT_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t t = tid; t < n; t += MSM_SORT_THREADS) {
+            const uint32_t word = dw[t];
+#pragma unroll
+            for (uint32_t hf = 0; hf < 2; ++hf) {
+                const uint32_t d16 = (word >> (16 * hf)) & 0xffffu, mag = d16 & 0x7fffu;
+                if (!mag) continue;
+                const uint32_t pos = atomicAdd(&hist[mag - 1], 1u);     // pass 0: count; pass 1: hist holds running positions
+                if (pass == 1) rec[pos] = (unsigned short)(t | (hf ? 0x4000u : 0u) | (d16 & 0x8000u));
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            // exclusive scan of the histogram: each thread owns a run of consecutive bins
+            const uint32_t per = (p.buckets + MSM_SORT_THREADS - 1) / MSM_SORT_THREADS, b0 = tid * per;
+            uint32_t local = 0;
+            for (uint32_t i = 0; i < per; ++i) if (b0 + i < p.buckets) local += hist[b0 + i];
+            part[tid] = local;
+            __syncthreads();
+            for (uint32_t d = 1; d < MSM_SORT_THREADS; d <<= 1) {
+                const uint32_t v = tid >= d ? part[tid - d] : 0;
+                __syncthreads();
+                part[tid] += v;
+                __syncthreads();
+            }
+            uint32_t run = part[tid] - local;
+            const size_t bin0 = (size_t)seg * p.buckets;
+            for (uint32_t i = 0; i < per; ++i) if (b0 + i < p.buckets) {
+                const uint32_t cnt = hist[b0 + i];
+                counts[bin0 + b0 + i] = cnt; offsets[bin0 + b0 + i] = run;
+                hist[b0 + i] = run;            // becomes the bin's running position for the scatter pass
+                run += cnt;
+            }
+            if (tid == MSM_SORT_THREADS - 1) seg_total[seg] = part[tid];
+            __syncthreads();
+        }
+    }
+    // the window's sorted list, one contiguous store; records widen to the list's 32-bit entries
+    const uint32_t total = part[MSM_SORT_THREADS - 1];
+    uint32_t* dst = list + (size_t)seg * stride;
+    for (uint32_t i = tid; i < total; i += MSM_SORT_THREADS) {
+        const uint32_t r = rec[i];
+        dst[i] = (r & 0x3fffu) | ((r & 0x4000u) ? MSM_ENTRY_HALF : 0u) | ((r & 0x8000u) ? MSM_ENTRY_NEG : 0u);
+    }
+}
+// seg_start[s] = logical start of segment s, seg_start[nseg] = counts[nb + 1] = E; zeroes the three control words
+__global__ void __launch_bounds__(1024) msm_seg_scan(const uint32_t* __restrict__ seg_total, uint32_t nseg, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ control) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nseg; base += 1024) {   // uniform trip count
+        const uint32_t i = base + t, c = i < nseg ? seg_total[i] : 0;
+        part[t] = c;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        if (i < nseg) seg_start[i] = carry + part[t] - c;
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) { seg_start[nseg] = carry; control[0] = 0; control[1] = carry; control[2] = 0; }
+}
+
 // the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y) — split into the load and the fix-up so that
 // the load of the next entry can be issued before the additions of the current one
 __device__ __forceinline__ G1A msm_entry_load(const MsmProblem& q, uint32_t e) {
@@ -361,11 +499,21 @@ __global__ void __launch_bounds__(1024) msm_offsets(const uint32_t* __restrict__
     if (i < nb) { offsets[i] = block_sums[blockIdx.x] + part[t] - c; cursor[i] = 0; }
 }
 
-// the bin that holds list position pos: the last b with offsets[b] <= pos (empty bins share the offset of the next non-empty one)
-__device__ __forceinline__ uint32_t msm_bin_of(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t pos) {
-    uint32_t lo = 0, hi = nb;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid; }
-    return lo;
+// The sorted list is LOGICALLY dense — entry positions 0 .. E in bin order, which is what the equal-length chunks of msm_accumulate
+// are cut from — but may be stored in SEGMENTS: segment s holds the bins [s * bps, (s + 1) * bps), its entries sit at
+// list[s * stride + i], its first logical position is seg_start[s], and offsets[b] is the bin's start INSIDE its segment.  The LDS
+// sort writes one segment per (problem, window) (each workgroup writes its own contiguous piece, no global prefix sum before the
+// stores); the global counting sort is the one-segment case (bps = all bins, seg_start = {0, E}).
+struct MsmSeg { const uint32_t* seg_start; uint32_t nseg, bps, stride; };
+__device__ __forceinline__ uint32_t msm_bin_start(const MsmSeg& g, const uint32_t* __restrict__ offsets, uint32_t b) { return g.seg_start[b / g.bps] + offsets[b]; }
+// the bin that holds logical position pos: the last bin whose start is <= pos (empty bins share the start of the next non-empty one)
+__device__ __forceinline__ uint32_t msm_bin_of(const MsmSeg& g, const uint32_t* __restrict__ offsets, uint32_t pos) {
+    uint32_t lo = 0, hi = g.nseg;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (g.seg_start[mid] <= pos) lo = mid; else hi = mid; }
+    const uint32_t base = lo * g.bps, local = pos - g.seg_start[lo];
+    lo = 0; hi = g.bps;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (offsets[base + mid] <= local) lo = mid; else hi = mid; }
+    return base + lo;
 }
 // Where the pieces of chunk `lane` go: a piece that is a whole bucket -> bucket_pts[b]; otherwise the chunk's first piece ->
 // partial[2*lane], its last -> partial[2*lane + 1] (a chunk has no other incomplete pieces).
@@ -376,16 +524,17 @@ __device__ __forceinline__ G1JSlot* msm_piece_dst(G1JSlot* __restrict__ bucket_p
 }
 // complete (slow, call-based) group law for the rare chunk in which a point meets itself or its negative
 __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                            const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E) {
+                                            const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E, MsmSeg g) {
     const uint32_t CH = msm_chunk_len(E);
     const uint32_t chunk_lo = lane * CH, chunk_hi = min(chunk_lo + CH, E);
-    uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
-    uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
+    uint32_t b = msm_bin_of(g, offsets, chunk_lo);
+    uint32_t bin_lo = msm_bin_start(g, offsets, b), bin_hi = bin_lo + counts[b];
     MsmProblem q = prs[b / nbq];
     G1J acc = G1J::identity();
     bool first = true;
     for (uint32_t pos = chunk_lo; pos < chunk_hi;) {
-        acc = g1_add_affine(acc, msm_entry_base(q, list[pos]));
+        const uint32_t sg = b / g.bps;
+        acc = g1_add_affine(acc, msm_entry_base(q, list[(size_t)sg * g.stride + (pos - g.seg_start[sg])]));
         ++pos;
         if (pos == bin_hi || pos == chunk_hi) {
             *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
@@ -399,7 +548,7 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
     }
 }
 __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb) {
+                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g) {
     const uint32_t E = counts[nb + 1];
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
     // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
@@ -411,14 +560,15 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
     const uint32_t chunk_lo = lane * CH;
     if (chunk_lo >= E) return;
     const uint32_t chunk_hi = min(chunk_lo + CH, E);
-    uint32_t b = msm_bin_of(offsets, nb, chunk_lo);
-    uint32_t bin_lo = offsets[b], bin_hi = bin_lo + counts[b];
+    uint32_t b = msm_bin_of(g, offsets, chunk_lo);
+    uint32_t sg = b / g.bps, seg_lo = g.seg_start[sg];      // the segment of the current bin and its first logical position
+    uint32_t bin_lo = seg_lo + offsets[b], bin_hi = bin_lo + counts[b];
     uint32_t qi = b / nbq;
     MsmProblem q = prs[qi];
     G1J acc = G1J::identity();
     bool first = true, ok = true;
     // software pipeline: the (random-access) load of entry pos + 1 is in flight during the ~2500 instructions of addition pos
-    uint32_t e_next = list[chunk_lo];
+    uint32_t e_next = list[(size_t)sg * g.stride + (chunk_lo - seg_lo)];
     G1A raw_next = msm_entry_load(q, e_next);
     for (uint32_t pos = chunk_lo; pos < chunk_hi && ok;) {
         const uint32_t e = e_next;
@@ -429,12 +579,14 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
         uint32_t b_next = b, lo_next = bin_lo, hi_next = bin_hi;
         if (pos == bin_hi && pos < chunk_hi) {
             do { ++b_next; } while (counts[b_next] == 0);   // pos < E: a later non-empty bin exists
-            lo_next = bin_hi; hi_next = lo_next + counts[b_next];
+            lo_next = bin_hi; hi_next = lo_next + counts[b_next];   // logically the list is dense: the next bin starts where this one ends
+            const uint32_t sn = b_next / g.bps;
+            if (sn != sg) { sg = sn; seg_lo = g.seg_start[sn]; }
         }
         const uint32_t qn = b_next / nbq;
         MsmProblem q_next = q;
         if (qn != qi) q_next = prs[qn];
-        if (pos < chunk_hi) { e_next = list[pos]; raw_next = msm_entry_load(q_next, e_next); }
+        if (pos < chunk_hi) { e_next = list[(size_t)sg * g.stride + (pos - seg_lo)]; raw_next = msm_entry_load(q_next, e_next); }
         ok = g1_madd_fast(acc, msm_entry_apply(raw, e));
         if (flush) {
             if (ok) *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
@@ -442,7 +594,7 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
         }
         b = b_next; bin_lo = lo_next; bin_hi = hi_next; qi = qn; q = q_next;
     }
-    if (!ok) msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E);  // redo the chunk with complete formulas
+    if (!ok) msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E, g);  // redo the chunk with complete formulas
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
@@ -458,10 +610,10 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
 // in counts[nb + 2]), and buckets spread over >= MSM_FIXUP_SERIAL chunks, from the back (counts[nb]).  Classifying first and
 // adding in a second, dense launch keeps the waves of the addition kernel full: only ~40 % of the buckets straddle.
 __global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ lists,
-                                                          G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
+                                                          G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    const uint32_t cnt = counts[b], off = offsets[b];
+    const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
     if (cnt == 0) { bucket_pts[b] = G1J::identity(); return; }
     const uint32_t CH = msm_chunk_len(counts[nb + 1]);
     const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
@@ -470,11 +622,11 @@ __global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__
     else lists[atomicAdd(&counts[nb + 2], 1u)] = b;
 }
 __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
-                                                const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
+                                                const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= counts[nb + 2]) return;
     const uint32_t b = lists[k];
-    const uint32_t cnt = counts[b], off = offsets[b];
+    const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
     const uint32_t CH = msm_chunk_len(counts[nb + 1]);
     const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
     // in-register additions; pieces of one bucket can coincide or cancel (the same point in two chunks): complete formulas then
@@ -485,14 +637,14 @@ __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ cou
     bucket_pts[b] = acc;
 }
 __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
-                                                                     const uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb) {
+                                                                     const uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
     __shared__ G1J red[MSM_HEAVY_THREADS];
     const uint32_t n_heavy = counts[nb];
     const uint32_t t = threadIdx.x;
     // every workgroup reaches the exit condition: the heavy list is complete before this kernel starts
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const uint32_t b = heavy[nb - 1 - h];
-        const uint32_t cnt = counts[b], off = offsets[b];
+        const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
         const uint32_t CH = msm_chunk_len(counts[nb + 1]);
         const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
         G1J acc = G1J::identity();
@@ -631,10 +783,11 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     if (count > MSM_MAX_PROBLEMS || count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
     uint32_t nmax = 0; size_t total = 0;
     for (uint32_t q = 0; q < count; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; }
+    uint32_t glv_next = 0;
     for (uint32_t q0 = 0; q0 < count; q0 += MSM_PROBLEM_CHUNK) {
         MsmProblemChunk ch;
         uint32_t k = std::min<uint32_t>(MSM_PROBLEM_CHUNK, count - q0);
-        for (uint32_t i = 0; i < k; ++i) ch.p[i] = pr.p[q0 + i];
+        for (uint32_t i = 0; i < k; ++i) { ch.p[i] = pr.p[q0 + i]; ch.p[i].glv_off = glv_next; glv_next += pr.p[q0 + i].n; }
         hipLaunchKernelGGL(msm_set_problems, dim3(1), dim3(64), 0, s, ch, k, ws.problems + q0);
     }
     if (nmax == 0) {
@@ -647,7 +800,21 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     MsmPlan p = msm_plan(nmax, msm_latency_bound(total));
     uint32_t nbq = p.windows * p.buckets, nb = nbq * count;
     if (nb > ws.cap_buckets || total * 2 * p.windows > ws.cap_list) { set_last_error("msm_enqueue_multi: workspace too small"); return H2V_ERR_BAD_ARGUMENT; }
+    // the sort: per (problem, window) inside LDS when a window's entries fit there, else the global counting sort
+    const uint32_t stride = 2 * nmax;
+    const size_t sort_lds = ((size_t)p.buckets + MSM_SORT_THREADS) * 4 + (size_t)stride * 2;
+    const bool lds_sort = nmax <= MSM_LDS_SORT_MAX_TERMS && sort_lds <= 150 * 1024 && (size_t)count * p.windows * stride <= ws.cap_list &&
+                          (size_t)count * p.windows <= (size_t)128 * ws.cap_problems && !getenv("H2V_MSM_GLOBAL_SORT");
+    MsmSeg g;
+    if (lds_sort) {
+        hipLaunchKernelGGL(msm_glv_prep, dim3((nmax + 255) / 256, count), dim3(256), 0, s, ws.problems, count, p, ws.glv);
+        if (sort_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        hipLaunchKernelGGL(msm_sort_lds, dim3(p.windows, count), dim3(MSM_SORT_THREADS), sort_lds, s, ws.problems, ws.glv, p, stride, ws.counts, ws.offsets, ws.list, ws.seg_total);
+        hipLaunchKernelGGL(msm_seg_scan, dim3(1), dim3(1024), 0, s, ws.seg_total, p.windows * count, ws.seg_start, ws.counts + nb);
+        g = MsmSeg{ws.seg_start, p.windows * count, p.buckets, stride};
+    } else {
     H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 3) * 4, s));
+    H2V_HIP_CHECK(hipMemsetAsync(ws.seg_start, 0, 4, s));   // one segment that starts at 0
     const uint32_t tiles = (nmax + MSM_TILE - 1) / MSM_TILE;
     dim3 gt(8 * ((count + 7) / 8) * tiles);
     const uint32_t wpp = std::max<uint32_t>(1u, std::min<uint32_t>(p.windows, MSM_LDS_WORDS / p.buckets));
@@ -658,15 +825,17 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     hipLaunchKernelGGL(msm_scan_sums, dim3(1), dim3(1024), 0, s, ws.block_sums, nblk, ws.counts + nb + 1);
     hipLaunchKernelGGL(msm_offsets, dim3(nblk), dim3(1024), 0, s, ws.counts, ws.block_sums, ws.offsets, ws.cursor, nb);
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, count, tiles, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
+    g = MsmSeg{ws.seg_start, 1, nb, 0};
+    }
     // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers its upper bound
     const size_t max_entries = total * 2 * p.windows;
     const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN);   // surplus workgroups return at once
     if (ws.profile) hipEventRecord(ws.ev_acc[0], s);
-    hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb);
+    hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g);
     if (ws.profile) { hipEventRecord(ws.ev_acc[1], s); ws.profile_recorded = true; }
-    hipLaunchKernelGGL(msm_fixup_classify, dim3((nb + 255) / 256), dim3(256), 0, s, ws.counts, ws.offsets, ws.cursor, ws.bucket_pts, nb);
-    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
-    hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb);
+    hipLaunchKernelGGL(msm_fixup_classify, dim3((nb + 255) / 256), dim3(256), 0, s, ws.counts, ws.offsets, ws.cursor, ws.bucket_pts, nb, g);
+    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
+    hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {
         const uint32_t T = msm_window_threads(p.buckets, p.windows * count);
         const size_t win_lds = (size_t)(T > 64 ? 4 : 3) * T * sizeof(G1J);   // 20 KB for one wave, 108 KB for four
