@@ -614,12 +614,21 @@ __global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
-    if (cnt == 0) { bucket_pts[b] = G1J::identity(); return; }
+    if (cnt == 0) bucket_pts[b] = G1J::identity();
     const uint32_t CH = msm_chunk_len(counts[nb + 1]);
-    const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
-    if (i0 == i1) return;  // written whole by its chunk
-    if (i1 - i0 >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&counts[nb], 1u)] = b;
-    else lists[atomicAdd(&counts[nb + 2], 1u)] = b;
+    const uint32_t i0 = off / CH, i1 = cnt ? (off + cnt - 1) / CH : i0;   // i0 == i1: written whole by its chunk (or empty)
+    const bool heavy = i1 - i0 >= MSM_FIXUP_SERIAL, straddles = i1 != i0 && !heavy;
+    if (heavy) lists[nb - 1 - atomicAdd(&counts[nb], 1u)] = b;   // rare
+    // ~40 % of the bins straddle: one atomic per WAVE on the shared cursor instead of one per bin (200 000 atomics on one address
+    // were 0.08 ms of a 20-step launch)
+    const unsigned long long mask = __ballot(straddles);
+    if (mask) {
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counts[nb + 2], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        if (straddles) lists[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = b;
+    }
 }
 __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                                 const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
