@@ -24,8 +24,8 @@ namespace h2v {
 __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
                                                    uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, uint8_t* __restrict__ ycanon,
                                                    int* __restrict__ status) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * np) return;
+    const uint32_t t_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = min(t_raw, n * np - 1);   // lanes past the end shadow the last point (all lanes reach the barriers below); their output is not stored
     uint32_t p = t / np, slot = t % np;
     const uint4* src = reinterpret_cast<const uint4*>(proofs + (size_t)p * proof_len + point_offsets[slot]);
     const uint4 lo = src[0], hi = src[1];
@@ -60,14 +60,27 @@ __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict_
         }
     }
     if (!ok) { status_set(status, p, slot < n_main_points ? H2V_DEV_ST_TRANSCRIPT : H2V_DEV_ST_OPENING); a = G1A::identity(); for (int i = 0; i < 8; ++i) yraw[i] = 0; }
-    // 72-byte point: nine 8-byte stores (72 p is always 8-byte aligned)
-    uint2* dp = reinterpret_cast<uint2*>(pts + ((size_t)p * np + slot));
+    // Outputs through LDS: consecutive lanes own consecutive points (t = proof * np + slot), so a wave's 64 points are 4608
+    // contiguous bytes and its 64 canonical y are 2048.  Written lane by lane (72-byte stride) every store instruction touched 36
+    // lines partially, and the L2 fetched each of them to merge the bytes: 0.2 GB of reads and 0.14 GB of writes for 26 MB of
+    // output (profiles/r02_pmc_fetch_write_steps20.csv, first collection).  Transposed in LDS, every store instruction writes
+    // 256 contiguous bytes.
+    __shared__ uint32_t out_lds[64 * 18];
+    const uint32_t lane = threadIdx.x, t0 = blockIdx.x * blockDim.x, live = min(64u, n * np - t0);
     const uint32_t* av = reinterpret_cast<const uint32_t*>(&a);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) dp[i] = make_uint2(av[2 * i], av[2 * i + 1]);
-    uint4* dy = reinterpret_cast<uint4*>(ycanon + ((size_t)p * np + slot) * 32);
-    dy[0] = make_uint4(yraw[0], yraw[1], yraw[2], yraw[3]);
-    dy[1] = make_uint4(yraw[4], yraw[5], yraw[6], yraw[7]);
+    for (int i = 0; i < 18; ++i) out_lds[lane * 18 + i] = av[i];
+    __syncthreads();
+    uint32_t* dp = reinterpret_cast<uint32_t*>(pts + t0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { const uint32_t k = i * 64 + lane; if (k < live * 18) dp[k] = out_lds[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out_lds[lane * 8 + i] = yraw[i];
+    __syncthreads();
+    uint32_t* dy = reinterpret_cast<uint32_t*>(ycanon + (size_t)t0 * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint32_t k = i * 64 + lane; if (k < live * 8) dy[k] = out_lds[k]; }
 }
 
 __global__ void __launch_bounds__(256) k_check_scalars(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ scalar_offsets,
