@@ -35,7 +35,7 @@ namespace h2v {
 
 #define N_LINES 102       // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
 #define PAIR_THREADS 128
-#define PAIR_REGS 10
+#define PAIR_REGS 17
 #define PAIR_MAX_OPS 512
 
 enum PairOpCode : uint32_t { P_SQR = 1, P_MUL = 2, P_MULL = 3, P_CONJ = 4, P_FROB = 5, P_INV2 = 6, P_COPY = 7, P_CHECK = 8 };
@@ -73,9 +73,30 @@ std::vector<uint32_t> pairing_program() {
     frob(T0, R); frob(T0, T0);
     mul(R, T0, R);                     // ^(p^2 + 1)
     // hard part: the x-power chain of Fuentes-Castaneda et al. (y0 .. y16); inverses in the cyclotomic subgroup are conjugates
-    auto pow_x = [&](uint32_t d, uint32_t a) {   // d = a^BN_X, d != a
-        copy(d, a);
-        for (int i = 61; i >= 0; --i) { sqr(d, d); if ((BN_X >> i) & 1) mul(d, d, a); }
+    // d = a^BN_X for a in the cyclotomic subgroup (a^-1 = conj(a)), d != a: width-4 signed windows over the exponent — the odd
+    // powers a, a^3, a^5, a^7 and their conjugates are tabulated (4 products + 4 conjugations), then 62 squarings and 13 products
+    // instead of the 27 of plain square-and-multiply: 10 fewer dependent Fq12 operations per x-power, 30 per pairing
+    const uint32_t TAB = 9;   // registers TAB + 2 j: a^(2j+1), TAB + 2 j + 1: its conjugate
+    auto pow_x = [&](uint32_t d, uint32_t a) {
+        std::vector<int> dig;   // width-4 non-adjacent form, least significant first
+        for (unsigned long long n = BN_X; n;) {
+            int z = 0;
+            if (n & 1) { z = (int)(n & 15); if (z >= 8) z -= 16; n -= (unsigned long long)(long long)z; }
+            dig.push_back(z);
+            n >>= 1;
+        }
+        copy(TAB, a);
+        sqr(d, a);                                   // a^2 (d is free until the main loop starts)
+        for (uint32_t j = 1; j < 4; ++j) mul(TAB + 2 * j, TAB + 2 * (j - 1), d);   // a^3, a^5, a^7
+        for (uint32_t j = 0; j < 4; ++j) conj(TAB + 2 * j + 1, TAB + 2 * j);
+        bool started = false;
+        for (size_t i = dig.size(); i-- > 0;) {
+            if (started) sqr(d, d);
+            const int z = dig[i];
+            if (!z) continue;
+            const uint32_t reg = TAB + 2 * (uint32_t)((z < 0 ? -z : z) >> 1) + (z < 0 ? 1 : 0);
+            if (started) mul(d, d, reg); else { copy(d, reg); started = true; }
+        }
     };
     const uint32_t y0 = T0, y1 = T1, y3 = T2, y4 = T3, y6 = T4, u = T5, v = T6;
     pow_x(y0, R); conj(y0, y0);        // y0 = r^-x
