@@ -96,28 +96,49 @@ __global__ void __launch_bounds__(256) k_check_scalars(const uint8_t* __restrict
     if (Fr::geq_p(raw)) status_set(status, p, i < ns ? H2V_DEV_ST_TRANSCRIPT : H2V_DEV_ST_INVALID_INSTANCES);
 }
 
+// One 8-byte word of the absorbed stream per thread, PROOF-MAJOR: words[proof][word].  Consecutive lanes build consecutive words
+// of one proof, so their source bytes are (mostly) consecutive bytes of that proof and the stores are contiguous; the hash kernels
+// then read a proof's 128-byte block as one line.  Round 1 had lanes = proofs: every byte load of a wave touched 64 different
+// lines (0.13 ms per 20-step launch for 37 MB of stream).
+#define STREAM_PROOFS_PER_BLOCK 8u   // a workgroup per proof was launch-rate bound: 20 480 workgroups of ~1 us of work each took 0.15 ms
 __global__ void __launch_bounds__(256) k_stream_build(const TranscriptSrc* __restrict__ stream, uint32_t stream_len, const uint8_t* __restrict__ proofs,
                                                       uint32_t proof_len, const uint8_t* __restrict__ ycanon, uint32_t np, const uint8_t* __restrict__ inst,
-                                                      uint32_t ninst, uint32_t n, unsigned long long* __restrict__ words) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t w = blockIdx.y;
-    if (p >= n) return;
-    unsigned long long v = 0;
-    for (uint32_t b = 0; b < 8; ++b) {
-        uint32_t pos = w * 8 + b;
-        if (pos >= stream_len) break;
-        TranscriptSrc s = stream[pos];  // wave-uniform
-        uint32_t byte;
-        switch (s.kind) {
-            case TranscriptSrc::CONST: byte = s.value; break;
-            case TranscriptSrc::PROOF: byte = proofs[(size_t)p * proof_len + s.offset]; break;
-            case TranscriptSrc::PROOF_MASKED: byte = proofs[(size_t)p * proof_len + s.offset] & 0x3f; break;
-            case TranscriptSrc::YCOORD: byte = ycanon[(size_t)p * np * 32 + s.offset]; break;
-            default: byte = inst[(size_t)p * ninst * 32 + s.offset]; break;
+                                                      uint32_t ninst, uint32_t n, uint32_t stream_words, unsigned long long* __restrict__ words) {
+    const uint32_t p0 = blockIdx.x * STREAM_PROOFS_PER_BLOCK, p1 = min(n, p0 + STREAM_PROOFS_PER_BLOCK);
+    for (uint32_t w = threadIdx.x; w < stream_words; w += blockDim.x) {
+        // the word's eight table entries are the same for every proof: read once, used for the block's proofs
+        uint32_t kind[8], value[8], off[8];
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) {
+            const uint32_t pos = w * 8 + b, q = pos < stream_len ? pos : stream_len - 1;
+            const TranscriptSrc sd = stream[q];
+            kind[b] = pos < stream_len ? sd.kind : (uint32_t)TranscriptSrc::CONST;
+            value[b] = pos < stream_len ? sd.value : 0u;
+            off[b] = kind[b] == TranscriptSrc::CONST ? 0u : sd.offset;
         }
-        v |= (unsigned long long)byte << (8 * b);
+        for (uint32_t p = p0; p < p1; ++p) {
+            const uint8_t* const pb = proofs + (size_t)p * proof_len;
+            const uint8_t* const yb = ycanon + (size_t)p * np * 32;
+            const uint8_t* const ib = inst + (size_t)p * ninst * 32;
+            // eight source addresses (selects, no branches: the kinds differ from lane to lane), eight byte loads back to back,
+            // constants and the flag mask merged afterwards
+            uint32_t raw[8];
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                const uint8_t* base = kind[b] == TranscriptSrc::YCOORD ? yb : (kind[b] == TranscriptSrc::INSTANCE ? ib : pb);
+                raw[b] = base[off[b]];
+            }
+            unsigned long long v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                uint32_t byte = raw[b];
+                if (kind[b] == TranscriptSrc::CONST) byte = value[b];
+                else if (kind[b] == TranscriptSrc::PROOF_MASKED) byte &= 0x3f;
+                v |= (unsigned long long)byte << (8 * b);
+            }
+            words[(size_t)p * stream_words + w] = v;
+        }
     }
-    words[(size_t)w * n + p] = v;
 }
 
 // ------------------------------------------------------------------ BLAKE2b (RFC 7693)
@@ -171,11 +192,12 @@ __device__ __forceinline__ void blake2b_compress_quad(unsigned long long& h0, un
 #define TR4_MSG_STRIDE 17   // 16 message words + 1: the sixteen proofs of a wave hit sixteen different LDS banks
 // squeeze_at[q] = absorbed length at which challenge q is produced: digest(stream[0..L)) with the state
 // cloned (transcript/mod.rs:209-214), 64 bytes -> Fr::from_uniform_bytes (:500-514).  16 proofs per wave.
-__global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __restrict__ words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
+__global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __restrict__ words_all, uint32_t stream_words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
                                                    uint32_t n, Fr* __restrict__ chal) {
     extern __shared__ unsigned long long tr_lds[];   // [16][TR4_MSG_STRIDE] message block, then [16][n_squeeze][8] digests
     const uint32_t tid = threadIdx.x, r = tid & 3u, pq = tid >> 2;
     const uint32_t p_raw = blockIdx.x * 16 + pq, p = p_raw < n ? p_raw : n - 1;   // lanes beyond n shadow the last proof (uniform control flow)
+    const unsigned long long* words = words_all + (size_t)p * stream_words;   // this proof's stream
     unsigned long long* msg = tr_lds + pq * TR4_MSG_STRIDE;
     unsigned long long* dig = tr_lds + 16 * TR4_MSG_STRIDE + (size_t)pq * n_squeeze * 8;
     uint32_t sig[12];
@@ -192,7 +214,7 @@ __global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __r
         for (; blk < last_blk; ++blk) {
             __syncthreads();
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) msg[4 * r + j] = words[((size_t)blk * 16 + 4 * r + j) * n + p];
+            for (uint32_t j = 0; j < 4; ++j) msg[4 * r + j] = words[(size_t)blk * 16 + 4 * r + j];
             __syncthreads();
             blake2b_compress_quad(h0, h1, msg, sig, (unsigned long long)(blk + 1) * 128, false, r);
         }
@@ -200,7 +222,7 @@ __global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __r
         __syncthreads();
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            unsigned long long w = words[((size_t)last_blk * 16 + 4 * r + j) * n + p];
+            unsigned long long w = words[(size_t)last_blk * 16 + 4 * r + j];
             const uint32_t lo = 8 * (4 * r + j);
             if (lo >= rem) w = 0;
             else if (lo + 8 > rem) w &= (1ULL << (8 * (rem - lo))) - 1;
@@ -253,7 +275,7 @@ __device__ __noinline__ void keccak_f1600(unsigned long long a[25]) {
     }
 }
 // digest of  stream[0..len) | suffix  given the running state `st` that has absorbed the first `blk` full 136-byte blocks
-__device__ __forceinline__ void keccak_tail(const unsigned long long st[25], const unsigned long long* __restrict__ words, uint32_t n, uint32_t p, uint32_t blk,
+__device__ __forceinline__ void keccak_tail(const unsigned long long st[25], const unsigned long long* __restrict__ words, uint32_t stream_words, uint32_t p, uint32_t blk,
                                             uint32_t len, uint32_t suffix, unsigned long long out[4]) {
     unsigned long long a[25];
     for (int i = 0; i < 25; ++i) a[i] = st[i];
@@ -262,7 +284,7 @@ __device__ __forceinline__ void keccak_tail(const unsigned long long st[25], con
         unsigned long long w = 0;
         uint32_t lo = 8 * j;
         if (lo < rem) {
-            w = words[((size_t)blk * 17 + j) * n + p];
+            w = words[(size_t)p * stream_words + (size_t)blk * 17 + j];
             if (lo + 8 > rem) w &= (1ULL << (8 * (rem - lo))) - 1;
         }
         if (rem >= lo && rem < lo + 8) w |= (unsigned long long)suffix << (8 * (rem - lo));
@@ -280,7 +302,7 @@ __device__ __forceinline__ void keccak_tail(const unsigned long long st[25], con
     for (int i = 0; i < 4; ++i) out[i] = a[i];
 }
 // stream words are laid out in 136-byte blocks here: word (blk * 17 + j)
-__global__ void __launch_bounds__(64) k_transcript_keccak(const unsigned long long* __restrict__ words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
+__global__ void __launch_bounds__(64) k_transcript_keccak(const unsigned long long* __restrict__ words, uint32_t stream_words, const uint32_t* __restrict__ squeeze_at, uint32_t n_squeeze,
                                                           uint32_t n, Fr* __restrict__ chal) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -291,12 +313,12 @@ __global__ void __launch_bounds__(64) k_transcript_keccak(const unsigned long lo
         uint32_t len = squeeze_at[q];
         uint32_t full = len / 136;
         for (; blk < full; ++blk) {
-            for (int j = 0; j < 17; ++j) st[j] ^= words[((size_t)blk * 17 + j) * n + p];
+            for (int j = 0; j < 17; ++j) st[j] ^= words[(size_t)p * stream_words + (size_t)blk * 17 + j];
             keccak_f1600(st);
         }
         unsigned long long lo[4], hi[4];
-        keccak_tail(st, words, n, p, blk, len, 10, lo);   // KECCAK256_PREFIX_CHALLENGE_LO
-        keccak_tail(st, words, n, p, blk, len, 11, hi);   // KECCAK256_PREFIX_CHALLENGE_HI
+        keccak_tail(st, words, stream_words, p, blk, len, 10, lo);   // KECCAK256_PREFIX_CHALLENGE_LO
+        keccak_tail(st, words, stream_words, p, blk, len, 11, hi);   // KECCAK256_PREFIX_CHALLENGE_HI
         uint32_t w32[16];
         for (int i = 0; i < 4; ++i) { w32[2 * i] = (uint32_t)lo[i]; w32[2 * i + 1] = (uint32_t)(lo[i] >> 32); w32[8 + 2 * i] = (uint32_t)hi[i]; w32[8 + 2 * i + 1] = (uint32_t)(hi[i] >> 32); }
         chal[(size_t)q * n + p] = Fr::from_uniform_words(w32);
@@ -539,15 +561,16 @@ int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
     const Plan& pl = *g.plan;
     uint32_t stream_len = (uint32_t)pl.stream.size();
     uint32_t n_words = g.stream_words;
-    hipLaunchKernelGGL(k_stream_build, dim3((n + 255) / 256, n_words), dim3(256), 0, s, g.pd->stream, stream_len, g.proofs, pl.proof_len, g.ycanon, pl.n_points, g.inst, pl.n_instance_values, n, g.words);
+    hipLaunchKernelGGL(k_stream_build, dim3((n + STREAM_PROOFS_PER_BLOCK - 1) / STREAM_PROOFS_PER_BLOCK), dim3(256), 0, s, g.pd->stream, stream_len, g.proofs, pl.proof_len, g.ycanon, pl.n_points, g.inst,
+                       pl.n_instance_values, n, n_words, g.words);
     if (pl.opts.transcript == H2V_TRANSCRIPT_KECCAK256)
-        hipLaunchKernelGGL(k_transcript_keccak, dim3((n + 63) / 64), dim3(64), 0, s, g.words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
+        hipLaunchKernelGGL(k_transcript_keccak, dim3((n + 63) / 64), dim3(64), 0, s, g.words, n_words, g.pd->squeeze_at, (uint32_t)pl.squeeze_at.size(), n, g.chal);
     else
     {
         const uint32_t nsq = (uint32_t)pl.squeeze_at.size();
         const size_t lds = ((size_t)16 * TR4_MSG_STRIDE + (size_t)16 * nsq * 8) * 8;
         if (lds > 60 * 1024) { set_last_error("transcript: too many challenges for one workgroup's LDS"); return H2V_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(k_transcript, dim3((n + 15) / 16), dim3(64), lds, s, g.words, g.pd->squeeze_at, nsq, n, g.chal);
+        hipLaunchKernelGGL(k_transcript, dim3((n + 15) / 16), dim3(64), lds, s, g.words, n_words, g.pd->squeeze_at, nsq, n, g.chal);
     }
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
