@@ -99,6 +99,8 @@ struct h2v_batch {
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
     uint32_t* fold_failed = nullptr;  // [groups] failed proofs reported by the folded shards (h2v_batch_fold_check_enqueue)
     h2v::MsmWorkspace ws;
+    h2v::MsmSplit split;              // how the last launch left its accumulators to the pairing (parts == 0: whole points in acc)
+    void* line_ws = nullptr; size_t line_ws_groups = 0;   // k_pair_lines' output, H2V_PAIRING_LINE_WS_BYTES per group
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
     uint32_t stream_words = 0;
     // profiling

@@ -110,6 +110,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
 }
 
 int close_enqueue(h2v_batch* b, bool with_pairing);
+#define H2V_SPLIT_MAX_GROUPS 64u
 
 int launch_impl(h2v_batch* b, int with_pairing) {
     if (!b || !b->plan) { set_last_error("h2v_batch_launch: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
@@ -173,7 +174,19 @@ int launch_impl(h2v_batch* b, int with_pairing) {
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
         }
         b->ws.profile = b->profiling; b->ws.profile_recorded = false;
-        if ((rc = msm_enqueue_multi(s, b->ws, pr))) return rc;
+        // A launch that ends in its own pairing checks leaves the accumulators in pieces (MsmSplit): the checks take the pieces, the
+        // whole points are put together beside them (close_enqueue).  Worth it while the launch is a latency chain, i.e. few groups.
+        b->split = MsmSplit();
+        static const uint32_t parts_knob = getenv("H2V_MSM_PARTS") ? (uint32_t)atoi(getenv("H2V_MSM_PARTS")) : 4u;
+        if (with_pairing && n && G <= H2V_SPLIT_MAX_GROUPS && parts_knob > 1) {
+            if (b->line_ws_groups < G) {
+                if (b->line_ws) { hipStreamSynchronize(s); hipFree(b->line_ws); b->line_ws = nullptr; b->line_ws_groups = 0; }
+                H2V_HIP_CHECK(hipMalloc(&b->line_ws, (size_t)G * H2V_PAIRING_LINE_WS_BYTES));
+                b->line_ws_groups = G;
+            }
+            b->split.want_parts = parts_knob;
+        }
+        if ((rc = msm_enqueue_multi(s, b->ws, pr, b->split.want_parts > 1 ? &b->split : nullptr))) return rc;
     }
     mark();
     if ((rc = close_enqueue(b, with_pairing != 0))) return rc;
@@ -191,9 +204,11 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     if (!with_pairing) return point_to_bytes_enqueue(s, b->acc, b->out_bytes, b->out_ident, 2 * G);
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork, s));
     H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
+    if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split))) return rc;   // acc <- the whole points
     if ((rc = point_to_bytes_enqueue(b->aux, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
     H2V_HIP_CHECK(hipEventRecord(b->ev_join, b->aux));
-    if ((rc = pairing_check_enqueue(s, b->ctx->pairing, b->acc, G, b->ok))) return rc;
+    if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.pts, G, b->split.parts, b->split.shift, b->line_ws, b->ok))) return rc; }
+    else if ((rc = pairing_check_enqueue(s, b->ctx->pairing, b->acc, G, b->ok))) return rc;
     H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join, 0));
     return 0;
 }
@@ -378,7 +393,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
     hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc); hipFree(b->ok);
-    hipFree(b->out_bytes); hipFree(b->out_ident); hipFree(b->fold_failed);
+    hipFree(b->out_bytes); hipFree(b->out_ident); hipFree(b->fold_failed); hipFree(b->line_ws);
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     if (b->aux) { hipStreamSynchronize(b->aux); hipStreamDestroy(b->aux); }
@@ -435,6 +450,7 @@ int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, 
     int rc;
     const uint32_t G = b->groups;
     if ((rc = fold_records_enqueue(b->stream, device_accumulators, (uint32_t)n_parts, G, b->acc, b->fold_failed))) return rc;
+    b->split = MsmSplit();   // the folded accumulators are whole points
     if ((rc = close_enqueue(b, true))) return rc;
     b->with_pairing = true;
     return 0;

@@ -69,6 +69,13 @@ struct alignas(128) G1JSlot {
     __host__ __device__ operator const G1J&() const { return p; }
 };
 
+#define MSM_MAX_PARTS 8
+struct MsmSplit {
+    uint32_t want_parts = 0;                        // in
+    uint32_t parts = 0, shift = 0, count = 0;       // out
+    const G1JSlot* pts = nullptr;                   // out: the workspace's piece array
+};
+
 struct MsmWorkspace {
     uint32_t cap_terms = 0, cap_problems = 0;
     uint32_t* counts = nullptr;   // [problems * windows * buckets + 3]  (last three words: number of heavy buckets, list cursor, number of straddling buckets)
@@ -77,6 +84,7 @@ struct MsmWorkspace {
     uint32_t* list = nullptr;     // term indices sorted by (problem, window, bucket)
     G1JSlot* bucket_pts = nullptr;  // [problems * windows * buckets]
     G1JSlot* window_sums = nullptr; // [problems * windows]
+    G1JSlot* pieces = nullptr;      // [problems * MSM_MAX_PARTS] partial Horner sums (MsmSplit)
     MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
@@ -92,7 +100,12 @@ struct MsmWorkspace {
     void release();
 };
 // Enqueue all problems of `pr` (each: sum_i scalars[i] * bases[i] -> *out, Jacobian, device memory).  Asynchronous on `s`.
-int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr);
+// With `split` (want_parts > 1) the Horner over the windows stops early: problem q is left as `parts` points
+//   pts[q * parts + j],   sum_i scalars[i] * bases[i] = sum_j 2^(shift * j) * pts[q * parts + j]
+// and *out is NOT written until msm_combine_enqueue (any stream ordered after `s`).  split->parts == 0 on return: the launch was
+// not cut (no terms, or a single window) and *out is written as without `split`.
+int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split = nullptr);
+int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp);
 int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, const G1A* d_bases, uint32_t n, G1J* d_out);
 
 // ------------------------------------------------------------------ small helpers (util.hip)

@@ -124,6 +124,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
     H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&pieces, (size_t)MSM_MAX_PARTS * max_problems * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
@@ -140,6 +141,8 @@ void MsmWorkspace::release() {
     if (list) hipFree(list);
     if (bucket_pts) hipFree(bucket_pts);
     if (window_sums) hipFree(window_sums);
+    if (pieces) hipFree(pieces);
+    pieces = nullptr;
     if (problems) hipFree(problems);
     if (block_sums) hipFree(block_sums);
     if (partial) hipFree(partial);
@@ -614,7 +617,6 @@ __global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
-    if (cnt == 0) bucket_pts[b] = G1J::identity();
     const uint32_t CH = msm_chunk_len(counts[nb + 1]);
     const uint32_t i0 = off / CH, i1 = cnt ? (off + cnt - 1) / CH : i0;   // i0 == i1: written whole by its chunk (or empty)
     const bool heavy = i1 - i0 >= MSM_FIXUP_SERIAL, straddles = i1 != i0 && !heavy;
@@ -679,7 +681,8 @@ __device__ __noinline__ void g1_dbl_to(G1J* dst, const G1J* a) { const G1J x = *
 // Here the group law is the shared out-of-line routine (one 35 KB body, complete formulas) and the three accumulators of a
 // lane live in LDS (dynamic: 3 x T points, + T for the four-wave tree): kept in private memory across the calls they cost
 // 0.35 GB of scratch write-backs per launch.
-__global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ window_sums, MsmPlan p) {
+// Empty buckets are recognised by their count: nobody writes an identity into their slots.
+__global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, const uint32_t* __restrict__ counts, G1JSlot* __restrict__ window_sums, MsmPlan p) {
     extern __shared__ G1J win_lds[];
     const uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x, T = blockDim.x;   // T: a power of two (msm_window_threads)
     G1J* run = win_lds + t;
@@ -690,8 +693,9 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
     const uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
     *run = G1J::identity(); *sum = G1J::identity();
     const G1JSlot* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
+    const uint32_t* cn = counts + ((size_t)q * p.windows + w) * p.buckets;
     for (uint32_t b = hi; b > lo; --b) {
-        g1_add_to(run, run, &bp[b - 1].p);
+        if (cn[b - 1]) g1_add_to(run, run, &bp[b - 1].p);
         g1_add_to(sum, sum, run);
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
@@ -763,20 +767,42 @@ __device__ __forceinline__ void g1_dbl_quad(G1J& p, uint32_t r) {
     p.X = X3;
     p.Z = YZ.dbl();
 }
+// Horner over the points src[0 .. items) (src[i] weighs 2^(dbl * i)) by the quad that lane r belongs to
+__device__ __forceinline__ G1J msm_horner_quad(const G1JSlot* __restrict__ src, uint32_t items, uint32_t dbl, uint32_t r) {
+    G1J acc = src[items - 1].p;
+    for (int w = (int)items - 2; w >= 0; --w) {
+        const G1J cur = src[w].p;   // in flight during the doublings
+#pragma unroll 1
+        for (uint32_t i = 0; i < dbl; ++i) g1_dbl_quad(acc, r);
+        acc = g1_add_inl(acc, cur);
+    }
+    return acc;
+}
 __global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3u;
     if (q >= count) return;   // whole quads
     G1J acc = G1J::identity();
-    if (prs[q].n) {
-        G1J next = window_sums[(size_t)q * p.windows + p.windows - 1];
-        for (int w = (int)p.windows - 1; w >= 0; --w) {
-            const G1J cur = next;
-            if (w > 0) next = window_sums[(size_t)q * p.windows + w - 1];   // in flight during the doublings
-#pragma unroll 1
-            for (uint32_t i = 0; i < p.c; ++i) g1_dbl_quad(acc, r);
-            acc = g1_add_inl(acc, cur);
-        }
-    }
+    if (prs[q].n) acc = msm_horner_quad(window_sums + (size_t)q * p.windows, p.windows, p.c, r);
+    if (r == 0) *prs[q].out = acc;
+}
+// The same Horner cut into `parts` pieces of `wpp` windows: part j = sum over its windows of 2^(c (w - j wpp)) S_w, so that
+//   result = sum_j 2^(c wpp j) part_j.
+// A batch's pairing check takes the pieces as they are — e(2^k A, Q) = e(A, 2^k Q), and the multiples of the two fixed G2 points
+// are tables of the context (pairing.hip) — so the ~130 dependent doublings of the full Horner leave the launch's critical path:
+// a piece is (wpp - 1) c of them.  The full sum (the accumulator a caller can read back) is put together beside the pairing.
+__global__ void __launch_bounds__(64) msm_final_parts(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p,
+                                                      uint32_t parts, uint32_t wpp, G1JSlot* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, quad = t >> 2, r = t & 3u;
+    if (quad >= count * parts) return;   // whole quads
+    const uint32_t q = quad / parts, j = quad % parts, lo = j * wpp, hi = min(p.windows, lo + wpp);
+    G1J acc = G1J::identity();
+    if (prs[q].n && lo < hi) acc = msm_horner_quad(window_sums + (size_t)q * p.windows + lo, hi - lo, p.c, r);
+    if (r == 0) out[quad] = acc;
+}
+__global__ void __launch_bounds__(64) msm_combine_parts(const G1JSlot* __restrict__ pieces, const MsmProblem* __restrict__ prs, uint32_t count, uint32_t parts, uint32_t shift) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3u;
+    if (q >= count) return;
+    const G1J acc = msm_horner_quad(pieces + (size_t)q * parts, parts, shift, r);
     if (r == 0) *prs[q].out = acc;
 }
 
@@ -786,7 +812,8 @@ __global__ void msm_set_problems(MsmProblemChunk ch, uint32_t count, MsmProblem*
     if (i < count) dst[i] = ch.p[i];
 }
 
-int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
+int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split) {
+    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; }
     const uint32_t count = (uint32_t)pr.p.size();
     if (count == 0) return 0;
     if (count > MSM_MAX_PROBLEMS || count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
@@ -849,9 +876,22 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
         const uint32_t T = msm_window_threads(p.buckets, p.windows * count);
         const size_t win_lds = (size_t)(T > 64 ? 4 : 3) * T * sizeof(G1J);   // 20 KB for one wave, 108 KB for four
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
-        hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(T), win_lds, s, ws.bucket_pts, ws.window_sums, p);
+        hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(T), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p);
     }
-    hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
+    if (split && split->want_parts > 1 && p.windows > 1) {
+        const uint32_t want = std::min<uint32_t>(split->want_parts, MSM_MAX_PARTS);
+        const uint32_t wpp = (p.windows + want - 1) / want, parts = (p.windows + wpp - 1) / wpp;
+        hipLaunchKernelGGL(msm_final_parts, dim3((4 * count * parts + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p, parts, wpp, ws.pieces);
+        split->parts = parts; split->shift = p.c * wpp; split->count = count; split->pts = ws.pieces;
+    } else {
+        hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
+    }
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp) {
+    if (!sp.parts) return 0;
+    hipLaunchKernelGGL(msm_combine_parts, dim3((4 * sp.count + 63) / 64), dim3(64), 0, s, sp.pts, ws.problems, sp.count, sp.parts, sp.shift);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

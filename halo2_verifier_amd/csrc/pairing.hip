@@ -33,7 +33,7 @@
 
 namespace h2v {
 
-#define N_LINES 102       // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
+#define N_LINES H2V_PAIRING_LINES
 #define PAIR_THREADS 128
 #define PAIR_REGS 17
 #define PAIR_MAX_OPS 512
@@ -126,8 +126,8 @@ std::vector<uint32_t> pairing_program() {
 }
 
 struct Coef { Fq c0, c1, n1; };   // an Fq2 coefficient and the negated imaginary part: n1 = -c1
-struct PairShared {
-    Fq2 line[N_LINES][5];         // per Miller step: l0(P0) * l1(P1), coefficients of w^0 .. w^4 (w^5 is zero)
+struct alignas(16) PairShared {
+    Fq2 line[N_LINES][6];         // per Miller step: the product of the step's line values, coefficients of w^0 .. w^5 (two lines: w^5 is zero)
     Fq2 prod[36];                 // partial products a_i * b_j at [6 i + j]
     Coef reg[PAIR_REGS][6];
     uint32_t prog[PAIR_MAX_OPS];  // the operation table, copied once: one LDS broadcast read per operation instead of a memory load
@@ -138,11 +138,16 @@ __device__ __forceinline__ int64_t p_times(int l, int64_t k) { return k * (int64
 
 __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
                                                           const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
-                                                          const uint32_t* __restrict__ prog, uint32_t n_ops, uint32_t* __restrict__ ok) {
+                                                          const uint32_t* __restrict__ prog, uint32_t n_ops, const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
     __shared__ PairShared s;
     const uint32_t chk = blockIdx.x, t = threadIdx.x;
     if (chk >= n) return;
-    {
+    if (pre) {
+        // the steps' line products come ready from k_pair_lines (a check over split accumulators: 2 * parts lines per step)
+        const uint4* src = reinterpret_cast<const uint4*>(pre + (size_t)chk * N_LINES * 6);
+        uint4* dst = reinterpret_cast<uint4*>(&s.line[0][0]);
+        for (uint32_t k = t; k < N_LINES * 6 * sizeof(Fq2) / 16; k += PAIR_THREADS) dst[k] = src[k];
+    } else {
         const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
         const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
         // line l(P) = a*y + b*x*w + c*w^3 with (x, y) = (X/Z^2, Y/Z^3); scaled by Z^3: a*Y + b*X*Z*w + c*Z^3*w^3
@@ -160,13 +165,14 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
             Fq2 ac = (a0 + c0) * (a1 + c1) - a0a1 - c0c1;
             Fq2 bc = (b0 + c0) * (b1 + c1) - b0b1 - c0c1;
             s.line[li][0] = a0a1 + c0c1.mul_xi(); s.line[li][1] = ab; s.line[li][2] = b0b1; s.line[li][3] = ac; s.line[li][4] = bc;
+            s.line[li][5] = Fq2::zero();
         }
-        if (t < 6) {
-            Coef c; c.c0 = t == 0 ? Fq::one() : Fq::zero(); c.c1 = Fq::zero(); c.n1 = Fq::zero();
-            s.reg[0][t] = c;
-        }
-        for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
     }
+    if (t < 6) {
+        Coef c; c.c0 = t == 0 ? Fq::one() : Fq::zero(); c.c1 = Fq::zero(); c.n1 = Fq::zero();
+        s.reg[0][t] = c;
+    }
+    for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
     __syncthreads();
     for (uint32_t pc = 0; pc < n_ops; ++pc) {
         const uint32_t w = s.prog[pc];   // uniform
@@ -195,8 +201,8 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
                 i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;
                 a0 = &s.reg[ra][i].c0; a1 = &s.reg[ra][i].c1; bb = &s.reg[rb][j];
             } else {
-                active = t < 60;
-                i = active ? pr / 5 : 0; j = active ? pr % 5 : 0;     // x_i * l_j
+                active = t < 72;
+                i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;     // x_i * l_j
                 a0 = &s.line[rb][j].c0; a1 = &s.line[rb][j].c1; bb = &s.reg[ra][i];
             }
             if (active) {
@@ -206,11 +212,6 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
                 Fq* dst = coord ? &s.prod[i * 6 + j].c1 : &s.prod[i * 6 + j].c0;
                 *dst = r;
                 if (op == P_SQR && i != j) { Fq* d2 = coord ? &s.prod[j * 6 + i].c1 : &s.prod[j * 6 + i].c0; *d2 = r; }
-            } else if (op == P_MULL && t < 72) {
-                // the line's w^5 coefficient is zero: lanes 60..71 clear the six products x_i * l_5
-                const uint32_t q = t - 60;
-                Fq* dst = (q & 1u) ? &s.prod[(q >> 1) * 6 + 5].c1 : &s.prod[(q >> 1) * 6 + 5].c0;
-                *dst = Fq::zero();
             }
             __syncthreads();
             // ---- fold: 18 outputs (coefficient k, kind 0 = re / 1 = im / 2 = -im), a quad of lanes each.  Lane 0 of the quad sums
@@ -284,10 +285,99 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
     }
 }
 
+// ---- line products for a check over SPLIT accumulators (msm.hip: msm_final_parts).  Check `chk` is
+//   prod_j e(L_j, 2^(shift j) s_g2) * e(R_j, -2^(shift j) g2) == 1,    L_j = pieces[(2 chk) S + j],  R_j = pieces[(2 chk + 1) S + j]:
+// 2 S Miller loops over the same 6x+2, i.e. 2 S line values per step, multiplied together here — every step of every check in
+// its own workgroup, all at once — so that the sequential part (k_pairing) still does ONE product per step whatever S is.
+// Per workgroup: the 2 S sparse values (a Y + b X Z w + c Z^3 w^3), S sparse x sparse Karatsuba products, then a binary tree
+// of general 6 x 6 products over Fq2[w]/(w^6 - xi).
+#define PL_THREADS 128
+struct PairLinesShared {
+    Fq2 ev[2 * MSM_MAX_PARTS][3];
+    Fq2 kar[MSM_MAX_PARTS][6];
+    Fq2 el[2][MSM_MAX_PARTS][6];
+    Fq2 prod[MSM_MAX_PARTS / 2][36];
+};
+__global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ pieces, uint32_t S, const LineCoeff* __restrict__ tab, Fq2* __restrict__ out) {
+    __shared__ PairLinesShared s;
+    const uint32_t step = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
+    // lane (line l = 2 j + side, coefficient k, component c)
+    for (uint32_t idx = t; idx < 2 * S * 6; idx += PL_THREADS) {
+        const uint32_t l = idx / 6, k = (idx % 6) >> 1, c = idx & 1u, j = l >> 1, side = l & 1u;
+        const G1J& P = pieces[(size_t)(2 * chk + side) * S + j].p;
+        const LineCoeff& q = tab[(size_t)l * N_LINES + step];
+        Fq r;
+        if (P.is_identity()) r = (k == 0 && c == 0) ? Fq::one() : Fq::zero();   // an identity point contributes the line value 1
+        else {
+            const Fq2& co = k == 0 ? q.a : (k == 1 ? q.b : q.c);
+            const Fq f = k == 0 ? P.Y : (k == 1 ? P.X : P.Z.sqr()) * P.Z;
+            r = (c ? co.c1 : co.c0) * f;
+        }
+        if (c) s.ev[l][k].c1 = r; else s.ev[l][k].c0 = r;
+    }
+    __syncthreads();
+    // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
+    for (uint32_t idx = t; idx < S * 6; idx += PL_THREADS) {
+        const uint32_t j = idx / 6, m = idx % 6;
+        const Fq2 *A = s.ev[2 * j], *B = s.ev[2 * j + 1];
+        const uint32_t u = m < 3 ? m : (m == 5 ? 1 : 0), v = m < 3 ? m : (m == 3 ? 1 : 2);   // m >= 3: (A_u + A_v)(B_u + B_v)
+        Fq2 x = A[u], y = B[u];
+        if (m >= 3) { x = x + A[v]; y = y + B[v]; }
+        s.kar[j][m] = x * y;
+    }
+    __syncthreads();
+    for (uint32_t idx = t; idx < S * 6; idx += PL_THREADS) {
+        const uint32_t j = idx / 6, k = idx % 6;
+        const Fq2* K = s.kar[j];
+        Fq2 r = Fq2::zero();
+        if (k == 0) r = K[0] + K[2].mul_xi();
+        else if (k == 1) r = K[3] - K[0] - K[1];
+        else if (k == 2) r = K[1];
+        else if (k == 3) r = K[4] - K[0] - K[2];
+        else if (k == 4) r = K[5] - K[1] - K[2];
+        s.el[0][j][k] = r;
+    }
+    __syncthreads();
+    uint32_t m = S, cur = 0;
+    while (m > 1) {   // uniform
+        const uint32_t np = m >> 1;
+        for (uint32_t idx = t; idx < np * 36; idx += PL_THREADS) {
+            const uint32_t p = idx / 36, ij = idx % 36;
+            s.prod[p][ij] = s.el[cur][2 * p][ij / 6] * s.el[cur][2 * p + 1][ij % 6];
+        }
+        __syncthreads();
+        for (uint32_t idx = t; idx < np * 6 + ((m & 1u) ? 6u : 0u); idx += PL_THREADS) {
+            const uint32_t p = idx / 6, k = idx % 6;
+            if (p == np) { s.el[cur ^ 1][np][k] = s.el[cur][m - 1][k]; continue; }   // the odd one out moves up as it is
+            Fq2 lo = Fq2::zero(), hi = Fq2::zero();
+            for (uint32_t i = 0; i <= k; ++i) lo = lo + s.prod[p][6 * i + (k - i)];
+            for (uint32_t i = k + 1; i < 6; ++i) hi = hi + s.prod[p][6 * i + (k + 6 - i)];
+            s.el[cur ^ 1][p][k] = lo + hi.mul_xi();
+        }
+        __syncthreads();
+        m = np + (m & 1u); cur ^= 1;
+    }
+    if (t < 6) out[((size_t)chk * N_LINES + step) * 6 + t] = s.el[cur][0][t];
+}
+
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok) {
     if (!n) return 0;
     if (!pd.prog || pd.n_ops > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
-    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, d_ok);
+    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, (const Fq2*)nullptr, d_ok);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_pieces, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok) {
+    if (!n) return 0;
+    if (!pd.prog || pd.n_ops > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
+    if (!parts || parts > MSM_MAX_PARTS || !d_line_ws) { set_last_error("pairing: bad split"); return H2V_ERR_BAD_ARGUMENT; }
+    const LineCoeff* tab = nullptr;
+    int rc = pd.split_lines(shift, parts, &tab);
+    if (rc) return rc;
+    Fq2* lines = reinterpret_cast<Fq2*>(d_line_ws);
+    hipLaunchKernelGGL(k_pair_lines, dim3(N_LINES, n), dim3(PL_THREADS), 0, s, d_pieces, parts, tab, lines);
+    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, (const Fq2*)lines, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -120,7 +120,8 @@ int PairingDevice::upload(const ParamsHost& p) {
     G2A ng2 = p.g2; ng2.y = ng2.y.neg();
     int na = g2_prepare(p.s_g2, k, a.data());
     int nb = g2_prepare(ng2, k, b.data());
-    (void)nb;
+    if (na != H2V_PAIRING_LINES || nb != H2V_PAIRING_LINES) { set_last_error("pairing: unexpected Miller loop length"); return H2V_ERR_DEVICE; }
+    h_sg2 = p.s_g2; h_ng2 = ng2;
     H2V_HIP_CHECK(hipMalloc(&l_sg2, sizeof(LineCoeff) * na));
     H2V_HIP_CHECK(hipMalloc(&l_ng2, sizeof(LineCoeff) * na));
     H2V_HIP_CHECK(hipMalloc(&consts, sizeof(PairingConsts)));
@@ -133,7 +134,39 @@ int PairingDevice::upload(const ParamsHost& p) {
     H2V_HIP_CHECK(hipMemcpy(prog, ops.data(), 4 * ops.size(), hipMemcpyHostToDevice));
     return 0;
 }
+// 2^shift * q by the Miller loop's own doubling step (homogeneous projective), back to affine
+static G2A g2_times_pow2(const G2A& q, uint32_t shift, const PairingConsts& k) {
+    if (!shift) return q;
+    G2Hom r = {q.x, q.y, Fq2::one()};
+    for (uint32_t i = 0; i < shift; ++i) (void)g2_dbl_step(r, k);
+    const Fq2 zi = r.z.inv();
+    return G2A{r.x * zi, r.y * zi, false};
+}
+int PairingDevice::split_lines(uint32_t shift, uint32_t parts, const LineCoeff** out) {
+    std::lock_guard<std::mutex> lock(split_mu);
+    for (const SplitTable& t : split) if (t.shift == shift && t.parts == parts) { *out = t.lines; return 0; }
+    const PairingConsts k = pairing_consts_host();
+    std::vector<LineCoeff> rows((size_t)2 * parts * H2V_PAIRING_LINES), one(MAX_LINE_COEFFS);
+    G2A a = h_sg2, b = h_ng2;
+    for (uint32_t j = 0; j < parts; ++j) {
+        if (j) { a = g2_times_pow2(a, shift, k); b = g2_times_pow2(b, shift, k); }
+        const G2A* side[2] = {&a, &b};
+        for (int sd = 0; sd < 2; ++sd) {
+            if (g2_prepare(*side[sd], k, one.data()) != H2V_PAIRING_LINES) { set_last_error("pairing: unexpected Miller loop length"); return H2V_ERR_DEVICE; }
+            std::copy(one.begin(), one.begin() + H2V_PAIRING_LINES, rows.begin() + (size_t)(2 * j + sd) * H2V_PAIRING_LINES);
+        }
+    }
+    LineCoeff* d = nullptr;
+    H2V_HIP_CHECK(hipMalloc(&d, sizeof(LineCoeff) * rows.size()));
+    hipError_t e = hipMemcpy(d, rows.data(), sizeof(LineCoeff) * rows.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d); set_last_error(std::string("pairing: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
+    split.push_back(SplitTable{shift, parts, d});
+    *out = d;
+    return 0;
+}
 void PairingDevice::release() {
+    for (SplitTable& t : split) if (t.lines) hipFree(t.lines);
+    split.clear();
     if (l_sg2) hipFree(l_sg2);
     if (l_ng2) hipFree(l_ng2);
     if (consts) hipFree(consts);
