@@ -177,7 +177,8 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         // A launch that ends in its own pairing checks leaves the accumulators in pieces (MsmSplit): the checks take the pieces, the
         // whole points are put together beside them (close_enqueue).  Worth it while the launch is a latency chain, i.e. few groups.
         b->split = MsmSplit();
-        static const uint32_t parts_knob = getenv("H2V_MSM_PARTS") ? (uint32_t)atoi(getenv("H2V_MSM_PARTS")) : 4u;
+        const char* parts_env = getenv("H2V_MSM_PARTS");   // tuning / test knob, read per launch
+        const uint32_t parts_knob = parts_env ? (uint32_t)atoi(parts_env) : 4u;
         if (with_pairing && n && G <= H2V_SPLIT_MAX_GROUPS && parts_knob > 1) {
             if (b->line_ws_groups < G) {
                 if (b->line_ws) { hipStreamSynchronize(s); hipFree(b->line_ws); b->line_ws = nullptr; b->line_ws_groups = 0; }
@@ -207,7 +208,7 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split))) return rc;   // acc <- the whole points
     if ((rc = point_to_bytes_enqueue(b->aux, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
     H2V_HIP_CHECK(hipEventRecord(b->ev_join, b->aux));
-    if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.pts, G, b->split.parts, b->split.shift, b->line_ws, b->ok))) return rc; }
+    if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.ready, G, b->split.parts, b->split.shift, b->line_ws, b->ok))) return rc; }
     else if ((rc = pairing_check_enqueue(s, b->ctx->pairing, b->acc, G, b->ok))) return rc;
     H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join, 0));
     return 0;

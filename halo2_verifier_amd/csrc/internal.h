@@ -74,6 +74,7 @@ struct MsmSplit {
     uint32_t want_parts = 0;                        // in
     uint32_t parts = 0, shift = 0, count = 0;       // out
     const G1JSlot* pts = nullptr;                   // out: the workspace's piece array
+    const G1JSlot* ready = nullptr;                 // out: the same pieces as (X Z, Y, Z^3), the form the Miller lines are evaluated at
 };
 
 struct MsmWorkspace {
@@ -84,7 +85,7 @@ struct MsmWorkspace {
     uint32_t* list = nullptr;     // term indices sorted by (problem, window, bucket)
     G1JSlot* bucket_pts = nullptr;  // [problems * windows * buckets]
     G1JSlot* window_sums = nullptr; // [problems * windows]
-    G1JSlot* pieces = nullptr;      // [problems * MSM_MAX_PARTS] partial Horner sums (MsmSplit)
+    G1JSlot* pieces = nullptr;      // [2][problems * MSM_MAX_PARTS] partial Horner sums (MsmSplit): Jacobian, then line-ready
     MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks

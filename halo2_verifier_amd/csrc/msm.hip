@@ -124,7 +124,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
     H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1JSlot)));
-    H2V_HIP_CHECK(hipMalloc(&pieces, (size_t)MSM_MAX_PARTS * max_problems * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&pieces, (size_t)2 * MSM_MAX_PARTS * max_problems * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
@@ -791,13 +791,16 @@ __global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ wind
 // are tables of the context (pairing.hip) — so the ~130 dependent doublings of the full Horner leave the launch's critical path:
 // a piece is (wpp - 1) c of them.  The full sum (the accumulator a caller can read back) is put together beside the pairing.
 __global__ void __launch_bounds__(64) msm_final_parts(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p,
-                                                      uint32_t parts, uint32_t wpp, G1JSlot* __restrict__ out) {
+                                                      uint32_t parts, uint32_t wpp, G1JSlot* __restrict__ out, G1JSlot* __restrict__ ready) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, quad = t >> 2, r = t & 3u;
     if (quad >= count * parts) return;   // whole quads
     const uint32_t q = quad / parts, j = quad % parts, lo = j * wpp, hi = min(p.windows, lo + wpp);
     G1J acc = G1J::identity();
     if (prs[q].n && lo < hi) acc = msm_horner_quad(window_sums + (size_t)q * p.windows + lo, hi - lo, p.c, r);
     if (r == 0) out[quad] = acc;
+    // the form the pairing's lines are evaluated at, (X Z, Y, Z^3): two lanes of the quad, two products deep
+    if (r == 0) { ready[quad].p.X = Fq::mul_inl(acc.X, acc.Z); ready[quad].p.Y = acc.Y; }
+    if (r == 1) ready[quad].p.Z = Fq::mul_inl(acc.Z.sqr_inl(), acc.Z);
 }
 __global__ void __launch_bounds__(64) msm_combine_parts(const G1JSlot* __restrict__ pieces, const MsmProblem* __restrict__ prs, uint32_t count, uint32_t parts, uint32_t shift) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3u;
@@ -813,7 +816,7 @@ __global__ void msm_set_problems(MsmProblemChunk ch, uint32_t count, MsmProblem*
 }
 
 int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split) {
-    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; }
+    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; split->ready = nullptr; }
     const uint32_t count = (uint32_t)pr.p.size();
     if (count == 0) return 0;
     if (count > MSM_MAX_PROBLEMS || count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
@@ -881,8 +884,8 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     if (split && split->want_parts > 1 && p.windows > 1) {
         const uint32_t want = std::min<uint32_t>(split->want_parts, MSM_MAX_PARTS);
         const uint32_t wpp = (p.windows + want - 1) / want, parts = (p.windows + wpp - 1) / wpp;
-        hipLaunchKernelGGL(msm_final_parts, dim3((4 * count * parts + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p, parts, wpp, ws.pieces);
-        split->parts = parts; split->shift = p.c * wpp; split->count = count; split->pts = ws.pieces;
+        hipLaunchKernelGGL(msm_final_parts, dim3((4 * count * parts + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p, parts, wpp, ws.pieces, ws.pieces + (size_t)MSM_MAX_PARTS * ws.cap_problems);
+        split->parts = parts; split->shift = p.c * wpp; split->count = count; split->pts = ws.pieces; split->ready = ws.pieces + (size_t)MSM_MAX_PARTS * ws.cap_problems;
     } else {
         hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
     }

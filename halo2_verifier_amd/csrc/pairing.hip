@@ -136,6 +136,45 @@ struct alignas(16) PairShared {
 // k-fold multiples of p on the limbs (offsets that keep the fold's integer combinations non-negative)
 __device__ __forceinline__ int64_t p_times(int l, int64_t k) { return k * (int64_t)FqParams::P29(l); }
 
+// The fold of one Fq12 product: prod[6 i + j] = a_i * b_j -> the six coefficients of the result, w^6 = xi applied.  Lanes t < 72
+// (whole quads): 18 outputs (coefficient k, kind 0 = re / 1 = im / 2 = -im), a quad of lanes each.  Lane 0 of the quad sums
+// the partial products with i + j = k ("low"), lane 1 those with i + j = k + 6 in the output's own coordinate, lane 2
+// the same entries in the other coordinate; lane 0 then collects the three sums (DPP quad broadcasts), applies
+// w^6 = xi = 9 + u as integer weights and reduces once.  One lane per output did all three sums one after the other —
+// twice the instructions on the critical path.
+__device__ __forceinline__ void fq12_fold(const Fq2* prod, Coef* dst, uint32_t t) {
+    const uint32_t o = t >> 2, role = t & 3u, k = o % 6, kind = o / 6;
+    const bool im = kind != 0;
+    // a_i b_j with i + j = k sits at entry k + 5 i (i <= k); with i + j = k + 6 at entry k + 6 + 5 i (i > k)
+    const bool same = role != 2;                           // which coordinate of the entry this lane adds up
+    const uint32_t first = role == 0 ? 0 : k + 1, last = role == 0 ? k + 1 : (role == 3 ? 0 : 6);
+    const Fq2* e = &prod[k + 5 * first + (role == 0 ? 0 : 6)];
+    const Fq* q = (im == same) ? &e->c1 : &e->c0;
+    uint32_t sum[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) sum[l] = 0;
+    for (uint32_t ii = first; ii < last; ++ii, q += 10) {   // 10 Fq = 5 entries
+#pragma unroll
+        for (int l = 0; l < 9; ++l) sum[l] += q->v[l];
+    }
+    // partial products are < 1.05p: re = lo + 9 hs - ho + 6p in (0, 60p); im = lo + 9 hs + ho < 59p; -im = 60p - im
+    int64_t acc[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+        const uint32_t hs = (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[l], 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
+        const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[l], 0xaa, 0xf, 0xf, true);   // quad_perm [2,2,2,2]
+        const int64_t pos = (int64_t)sum[l] + 9 * (int64_t)hs;
+        if (kind == 0) acc[l] = pos - (int64_t)ho + p_times(l, 6);
+        else if (kind == 1) acc[l] = pos + (int64_t)ho;
+        else acc[l] = p_times(l, 60) - pos - (int64_t)ho;
+    }
+    if (role == 0) {
+        const Fq r = Fq::from_wide(acc);
+        Coef* out = &dst[k];
+        if (kind == 0) out->c0 = r; else if (kind == 1) out->c1 = r; else out->n1 = r;
+    }
+}
+
 __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
                                                           const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
                                                           const uint32_t* __restrict__ prog, uint32_t n_ops, const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
@@ -214,43 +253,8 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
                 if (op == P_SQR && i != j) { Fq* d2 = coord ? &s.prod[j * 6 + i].c1 : &s.prod[j * 6 + i].c0; *d2 = r; }
             }
             __syncthreads();
-            // ---- fold: 18 outputs (coefficient k, kind 0 = re / 1 = im / 2 = -im), a quad of lanes each.  Lane 0 of the quad sums
-            // the partial products with i + j = k ("low"), lane 1 those with i + j = k + 6 in the output's own coordinate, lane 2
-            // the same entries in the other coordinate; lane 0 then collects the three sums (DPP quad broadcasts), applies
-            // w^6 = xi = 9 + u as integer weights and reduces once.  One lane per output did all three sums one after the other —
-            // twice the instructions on the critical path.
-            if (t < 72) {
-                const uint32_t o = t >> 2, role = t & 3u, k = o % 6, kind = o / 6;
-                const bool im = kind != 0;
-                // a_i b_j with i + j = k sits at entry k + 5 i (i <= k); with i + j = k + 6 at entry k + 6 + 5 i (i > k)
-                const bool same = role != 2;                           // which coordinate of the entry this lane adds up
-                const uint32_t first = role == 0 ? 0 : k + 1, last = role == 0 ? k + 1 : (role == 3 ? 0 : 6);
-                const Fq2* e = &s.prod[k + 5 * first + (role == 0 ? 0 : 6)];
-                const Fq* q = (im == same) ? &e->c1 : &e->c0;
-                uint32_t sum[9];
-#pragma unroll
-                for (int l = 0; l < 9; ++l) sum[l] = 0;
-                for (uint32_t ii = first; ii < last; ++ii, q += 10) {   // 10 Fq = 5 entries
-#pragma unroll
-                    for (int l = 0; l < 9; ++l) sum[l] += q->v[l];
-                }
-                // partial products are < 1.05p: re = lo + 9 hs - ho + 6p in (0, 60p); im = lo + 9 hs + ho < 59p; -im = 60p - im
-                int64_t acc[9];
-#pragma unroll
-                for (int l = 0; l < 9; ++l) {
-                    const uint32_t hs = (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[l], 0x55, 0xf, 0xf, true);   // quad_perm [1,1,1,1]
-                    const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[l], 0xaa, 0xf, 0xf, true);   // quad_perm [2,2,2,2]
-                    const int64_t pos = (int64_t)sum[l] + 9 * (int64_t)hs;
-                    if (kind == 0) acc[l] = pos - (int64_t)ho + p_times(l, 6);
-                    else if (kind == 1) acc[l] = pos + (int64_t)ho;
-                    else acc[l] = p_times(l, 60) - pos - (int64_t)ho;
-                }
-                if (role == 0) {
-                    const Fq r = Fq::from_wide(acc);
-                    Coef* dst = &s.reg[rd][k];
-                    if (kind == 0) dst->c0 = r; else if (kind == 1) dst->c1 = r; else dst->n1 = r;
-                }
-            }
+            // ---- fold
+            if (t < 72) fq12_fold(s.prod, s.reg[rd], t);
             __syncthreads();
         } else if (op == P_CHECK) {
             if (t == 0) {
@@ -286,78 +290,95 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
 }
 
 // ---- line products for a check over SPLIT accumulators (msm.hip: msm_final_parts).  Check `chk` is
-//   prod_j e(L_j, 2^(shift j) s_g2) * e(R_j, -2^(shift j) g2) == 1,    L_j = pieces[(2 chk) S + j],  R_j = pieces[(2 chk + 1) S + j]:
+//   prod_j e(L_j, 2^(shift j) s_g2) * e(R_j, -2^(shift j) g2) == 1,    L_j = piece (2 chk) S + j,  R_j = piece (2 chk + 1) S + j:
 // 2 S Miller loops over the same 6x+2, i.e. 2 S line values per step, multiplied together here — every step of every check in
 // its own workgroup, all at once — so that the sequential part (k_pairing) still does ONE product per step whatever S is.
-// Per workgroup: the 2 S sparse values (a Y + b X Z w + c Z^3 w^3), S sparse x sparse Karatsuba products, then a binary tree
-// of general 6 x 6 products over Fq2[w]/(w^6 - xi).
-#define PL_THREADS 128
+// Per workgroup: the 2 S sparse values (a Y + b X Z w + c Z^3 w^3; the pieces arrive as (X Z, Y, Z^3)), the S sparse x sparse
+// products, then a binary tree of general products over Fq2[w]/(w^6 - xi) — the same dot2 lanes and fold as k_pairing.
+#define PL_THREADS 192          // two general products per pass (72 lanes each)
+#define PL_MAX_PARTS 8
 struct PairLinesShared {
-    Fq2 ev[2 * MSM_MAX_PARTS][3];
-    Fq2 kar[MSM_MAX_PARTS][6];
-    Fq2 el[2][MSM_MAX_PARTS][6];
-    Fq2 prod[MSM_MAX_PARTS / 2][36];
+    Coef el[2][PL_MAX_PARTS][6];                    // the tree's elements, ping-pong
+    union {
+        struct { Coef ev[2 * PL_MAX_PARTS][3]; Fq2 sp[PL_MAX_PARTS][9]; } l;   // line values (w^0, w^1, w^3) and the sparse products A_u * B_v at [3 u + v]
+        Fq2 prod[2][36];                            // partial products of the general products in flight
+    } u;
 };
-__global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ pieces, uint32_t S, const LineCoeff* __restrict__ tab, Fq2* __restrict__ out) {
+__global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ ready, uint32_t S, const LineCoeff* __restrict__ tab, Fq2* __restrict__ out) {
     __shared__ PairLinesShared s;
     const uint32_t step = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
-    // lane (line l = 2 j + side, coefficient k, component c)
+    // line l = 2 j + side at the point ready[(2 chk + side) S + j] = (X Z, Y, Z^3): a Y + b (X Z) w + c Z^3 w^3.  Lane (l, k, component).
     for (uint32_t idx = t; idx < 2 * S * 6; idx += PL_THREADS) {
         const uint32_t l = idx / 6, k = (idx % 6) >> 1, c = idx & 1u, j = l >> 1, side = l & 1u;
-        const G1J& P = pieces[(size_t)(2 * chk + side) * S + j].p;
+        const G1J& P = ready[(size_t)(2 * chk + side) * S + j].p;
         const LineCoeff& q = tab[(size_t)l * N_LINES + step];
-        Fq r;
+        const Fq2& co = k == 0 ? q.a : (k == 1 ? q.b : q.c);
+        const Fq& f = k == 0 ? P.Y : (k == 1 ? P.X : P.Z);
+        Fq r = Fq::mul_inl(c ? co.c1 : co.c0, f);
         if (P.is_identity()) r = (k == 0 && c == 0) ? Fq::one() : Fq::zero();   // an identity point contributes the line value 1
-        else {
-            const Fq2& co = k == 0 ? q.a : (k == 1 ? q.b : q.c);
-            const Fq f = k == 0 ? P.Y : (k == 1 ? P.X : P.Z.sqr()) * P.Z;
-            r = (c ? co.c1 : co.c0) * f;
+        Coef& e = s.u.l.ev[l][k];
+        if (c) { e.c1 = r; e.n1 = r.neg(); } else e.c0 = r;
+    }
+    __syncthreads();
+    // the S sparse x sparse products, nine Fq2 products each: lane (j, u, v, coordinate), one dot2
+    for (uint32_t idx = t; idx < S * 18; idx += PL_THREADS) {
+        const uint32_t j = idx / 18, pr = (idx % 18) >> 1, coord = idx & 1u;
+        const Coef& a = s.u.l.ev[2 * j][pr / 3];
+        const Coef& b = s.u.l.ev[2 * j + 1][pr % 3];
+        const Fq r = Fq::dot2_inl(a.c0, coord ? b.c1 : b.c0, a.c1, coord ? b.c0 : b.n1);
+        if (coord) s.u.l.sp[j][pr].c1 = r; else s.u.l.sp[j][pr].c0 = r;
+    }
+    __syncthreads();
+    // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4:
+    // lane (j, coefficient k, kind re / im / -im): at most two entries, xi as integer weights, one from_wide
+    for (uint32_t idx = t; idx < S * 18; idx += PL_THREADS) {
+        const uint32_t j = idx / 18, k = (idx % 18) / 3, kind = idx % 3;
+        Fq r = Fq::zero();
+        if (k < 5) {
+            const uint32_t i1 = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 4 : (k == 3 ? 2 : 5)));
+            const uint32_t i2 = k == 0 ? 8 : (k == 1 ? 3 : (k == 3 ? 6 : 7));
+            const Fq2& x = s.u.l.sp[j][i1];
+            const Fq2& y = s.u.l.sp[j][i2];
+            const bool im = kind != 0;
+            const Fq& xs = im ? x.c1 : x.c0;            // the output's own coordinate
+            const Fq& ys = im ? y.c1 : y.c0;
+            const Fq& yo = im ? y.c0 : y.c1;            // the other one (xi couples them)
+            const int64_t wy = k == 2 ? 0 : (k == 0 ? 9 : 1), wo = k == 0 ? (im ? 1 : -1) : 0;
+            int64_t acc[9];
+#pragma unroll
+            for (int lm = 0; lm < 9; ++lm) {
+                const int64_t v = (int64_t)xs.v[lm] + wy * (int64_t)ys.v[lm] + wo * (int64_t)yo.v[lm];   // in (-1.05p, 12p)
+                acc[lm] = kind == 2 ? p_times(lm, 14) - v : v + p_times(lm, 2);
+            }
+            r = Fq::from_wide(acc);
         }
-        if (c) s.ev[l][k].c1 = r; else s.ev[l][k].c0 = r;
+        Coef& e = s.el[0][j][k];
+        if (kind == 0) e.c0 = r; else if (kind == 1) e.c1 = r; else e.n1 = r;
     }
     __syncthreads();
-    // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
-    for (uint32_t idx = t; idx < S * 6; idx += PL_THREADS) {
-        const uint32_t j = idx / 6, m = idx % 6;
-        const Fq2 *A = s.ev[2 * j], *B = s.ev[2 * j + 1];
-        const uint32_t u = m < 3 ? m : (m == 5 ? 1 : 0), v = m < 3 ? m : (m == 3 ? 1 : 2);   // m >= 3: (A_u + A_v)(B_u + B_v)
-        Fq2 x = A[u], y = B[u];
-        if (m >= 3) { x = x + A[v]; y = y + B[v]; }
-        s.kar[j][m] = x * y;
-    }
-    __syncthreads();
-    for (uint32_t idx = t; idx < S * 6; idx += PL_THREADS) {
-        const uint32_t j = idx / 6, k = idx % 6;
-        const Fq2* K = s.kar[j];
-        Fq2 r = Fq2::zero();
-        if (k == 0) r = K[0] + K[2].mul_xi();
-        else if (k == 1) r = K[3] - K[0] - K[1];
-        else if (k == 2) r = K[1];
-        else if (k == 3) r = K[4] - K[0] - K[2];
-        else if (k == 4) r = K[5] - K[1] - K[2];
-        s.el[0][j][k] = r;
-    }
-    __syncthreads();
+    // binary tree of general products, two per pass
     uint32_t m = S, cur = 0;
     while (m > 1) {   // uniform
         const uint32_t np = m >> 1;
-        for (uint32_t idx = t; idx < np * 36; idx += PL_THREADS) {
-            const uint32_t p = idx / 36, ij = idx % 36;
-            s.prod[p][ij] = s.el[cur][2 * p][ij / 6] * s.el[cur][2 * p + 1][ij % 6];
+        for (uint32_t p0 = 0; p0 < np; p0 += 2) {
+            const uint32_t slot = t / 72, lt = t % 72, p = p0 + slot;
+            const bool on = slot < 2 && p < np;
+            if (on) {
+                const uint32_t pr = lt >> 1, coord = lt & 1u, i = pr / 6, j = pr % 6;
+                const Coef& a = s.el[cur][2 * p][i];
+                const Coef& b = s.el[cur][2 * p + 1][j];
+                const Fq r = Fq::dot2_inl(a.c0, coord ? b.c1 : b.c0, a.c1, coord ? b.c0 : b.n1);
+                if (coord) s.u.prod[slot][pr].c1 = r; else s.u.prod[slot][pr].c0 = r;
+            }
+            __syncthreads();
+            if (on) fq12_fold(s.u.prod[slot], s.el[cur ^ 1][p], lt);
+            __syncthreads();
         }
-        __syncthreads();
-        for (uint32_t idx = t; idx < np * 6 + ((m & 1u) ? 6u : 0u); idx += PL_THREADS) {
-            const uint32_t p = idx / 6, k = idx % 6;
-            if (p == np) { s.el[cur ^ 1][np][k] = s.el[cur][m - 1][k]; continue; }   // the odd one out moves up as it is
-            Fq2 lo = Fq2::zero(), hi = Fq2::zero();
-            for (uint32_t i = 0; i <= k; ++i) lo = lo + s.prod[p][6 * i + (k - i)];
-            for (uint32_t i = k + 1; i < 6; ++i) hi = hi + s.prod[p][6 * i + (k + 6 - i)];
-            s.el[cur ^ 1][p][k] = lo + hi.mul_xi();
-        }
+        if ((m & 1u) && t < 6) s.el[cur ^ 1][np][t] = s.el[cur][m - 1][t];   // the odd one out moves up as it is
         __syncthreads();
         m = np + (m & 1u); cur ^= 1;
     }
-    if (t < 6) out[((size_t)chk * N_LINES + step) * 6 + t] = s.el[cur][0][t];
+    if (t < 6) out[((size_t)chk * N_LINES + step) * 6 + t] = Fq2{s.el[cur][0][t].c0, s.el[cur][0][t].c1};
 }
 
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok) {
@@ -368,15 +389,15 @@ int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_p
     return 0;
 }
 
-int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_pieces, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok) {
+int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_ready, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok) {
     if (!n) return 0;
     if (!pd.prog || pd.n_ops > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
-    if (!parts || parts > MSM_MAX_PARTS || !d_line_ws) { set_last_error("pairing: bad split"); return H2V_ERR_BAD_ARGUMENT; }
+    if (!parts || parts > PL_MAX_PARTS || !d_line_ws) { set_last_error("pairing: bad split"); return H2V_ERR_BAD_ARGUMENT; }
     const LineCoeff* tab = nullptr;
     int rc = pd.split_lines(shift, parts, &tab);
     if (rc) return rc;
     Fq2* lines = reinterpret_cast<Fq2*>(d_line_ws);
-    hipLaunchKernelGGL(k_pair_lines, dim3(N_LINES, n), dim3(PL_THREADS), 0, s, d_pieces, parts, tab, lines);
+    hipLaunchKernelGGL(k_pair_lines, dim3(N_LINES, n), dim3(PL_THREADS), 0, s, d_ready, parts, tab, lines);
     hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, (const Fq2*)lines, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
