@@ -178,7 +178,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         // whole points are put together beside them (close_enqueue).  Worth it while the launch is a latency chain, i.e. few groups.
         b->split = MsmSplit();
         const char* parts_env = getenv("H2V_MSM_PARTS");   // tuning / test knob, read per launch
-        const uint32_t parts_knob = parts_env ? (uint32_t)atoi(parts_env) : 4u;
+        const uint32_t parts_knob = parts_env ? (uint32_t)atoi(parts_env) : MSM_MAX_PARTS;
         if (with_pairing && n && G <= H2V_SPLIT_MAX_GROUPS && parts_knob > 1) {
             if (b->line_ws_groups < G) {
                 if (b->line_ws) { hipStreamSynchronize(s); hipFree(b->line_ws); b->line_ws = nullptr; b->line_ws_groups = 0; }

@@ -69,7 +69,7 @@ struct alignas(128) G1JSlot {
     __host__ __device__ operator const G1J&() const { return p; }
 };
 
-#define MSM_MAX_PARTS 8
+#define MSM_MAX_PARTS 6
 struct MsmSplit {
     uint32_t want_parts = 0;                        // in
     uint32_t parts = 0, shift = 0, count = 0;       // out

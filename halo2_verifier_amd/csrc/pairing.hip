@@ -34,6 +34,7 @@
 namespace h2v {
 
 #define N_LINES H2V_PAIRING_LINES
+#define PAIR_ITERS 66        // line products of the merged program: 64 Miller iterations + the two Frobenius corrections
 #define PAIR_THREADS 128
 #define PAIR_REGS 17
 #define PAIR_MAX_OPS 512
@@ -42,7 +43,7 @@ enum PairOpCode : uint32_t { P_SQR = 1, P_MUL = 2, P_MULL = 3, P_CONJ = 4, P_FRO
 static inline uint32_t pair_op(uint32_t op, uint32_t d, uint32_t a, uint32_t b) { return op | (d << 8) | (a << 16) | (b << 24); }
 
 // The operation table of one pairing check (host, once per context).  Registers: 0 = f, 1 = r, 2.. = temporaries.
-std::vector<uint32_t> pairing_program() {
+std::vector<uint32_t> pairing_program(bool merged) {
     std::vector<uint32_t> p;
     enum { F = 0, R = 1, T0 = 2, T1 = 3, T2 = 4, T3 = 5, T4 = 6, T5 = 7, T6 = 8 };
     auto sqr = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_SQR, d, a, 0)); };
@@ -51,11 +52,13 @@ std::vector<uint32_t> pairing_program() {
     auto frob = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_FROB, d, a, 0)); };
     auto copy = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_COPY, d, a, 0)); };
     // Miller loop: one squaring and one line product per doubling step, one more line product per addition step
+    // (merged: the doubling and addition lines of one iteration arrive already multiplied together, k_pair_lines: one line
+    // product per iteration, 36 fewer dependent operations)
     uint32_t idx = 0;
     for (int i = 63; i >= 0; --i) {
         sqr(F, F);
         p.push_back(pair_op(P_MULL, F, F, idx++));
-        if ((ATE_LOW >> i) & 1) p.push_back(pair_op(P_MULL, F, F, idx++));
+        if (!merged && ((ATE_LOW >> i) & 1)) p.push_back(pair_op(P_MULL, F, F, idx++));
     }
     p.push_back(pair_op(P_MULL, F, F, idx++));
     p.push_back(pair_op(P_MULL, F, F, idx++));
@@ -150,12 +153,19 @@ __device__ __forceinline__ void fq12_fold(const Fq2* prod, Coef* dst, uint32_t t
     const uint32_t first = role == 0 ? 0 : k + 1, last = role == 0 ? k + 1 : (role == 3 ? 0 : 6);
     const Fq2* e = &prod[k + 5 * first + (role == 0 ? 0 : 6)];
     const Fq* q = (im == same) ? &e->c1 : &e->c0;
+    // a fixed six steps with the loads of all of them in flight at once (a loop over [first, last) waited for LDS every round;
+    // the lanes of a quad differ in their counts, so the wave ran the maximum anyway): entries outside the lane's range are masked
     uint32_t sum[9];
 #pragma unroll
     for (int l = 0; l < 9; ++l) sum[l] = 0;
-    for (uint32_t ii = first; ii < last; ++ii, q += 10) {   // 10 Fq = 5 entries
+    const uint32_t cnt = last > first ? last - first : 0;
+    if (!cnt) q = &prod[0].c0;                          // an idle lane reads a valid entry (masked)
 #pragma unroll
-        for (int l = 0; l < 9; ++l) sum[l] += q->v[l];
+    for (uint32_t ii = 0; ii < 6; ++ii) {
+        const Fq* qq = q + 10 * (ii < cnt ? ii : 0);   // 10 Fq = 5 entries
+        const uint32_t msk = ii < cnt ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) sum[l] += qq->v[l] & msk;
     }
     // partial products are < 1.05p: re = lo + 9 hs - ho + 6p in (0, 60p); im = lo + 9 hs + ho < 59p; -im = 60p - im
     int64_t acc[9];
@@ -183,9 +193,9 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
     if (chk >= n) return;
     if (pre) {
         // the steps' line products come ready from k_pair_lines (a check over split accumulators: 2 * parts lines per step)
-        const uint4* src = reinterpret_cast<const uint4*>(pre + (size_t)chk * N_LINES * 6);
+        const uint4* src = reinterpret_cast<const uint4*>(pre + (size_t)chk * PAIR_ITERS * 6);
         uint4* dst = reinterpret_cast<uint4*>(&s.line[0][0]);
-        for (uint32_t k = t; k < N_LINES * 6 * sizeof(Fq2) / 16; k += PAIR_THREADS) dst[k] = src[k];
+        for (uint32_t k = t; k < PAIR_ITERS * 6 * sizeof(Fq2) / 16; k += PAIR_THREADS) dst[k] = src[k];
     } else {
         const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
         const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
@@ -291,28 +301,33 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
 
 // ---- line products for a check over SPLIT accumulators (msm.hip: msm_final_parts).  Check `chk` is
 //   prod_j e(L_j, 2^(shift j) s_g2) * e(R_j, -2^(shift j) g2) == 1,    L_j = piece (2 chk) S + j,  R_j = piece (2 chk + 1) S + j:
-// 2 S Miller loops over the same 6x+2, i.e. 2 S line values per step, multiplied together here — every step of every check in
-// its own workgroup, all at once — so that the sequential part (k_pairing) still does ONE product per step whatever S is.
+// 2 S Miller loops over the same 6x+2, i.e. 2 S line values per step, multiplied together here — every ITERATION (its doubling
+// step and its addition step if it has one; the two Frobenius corrections count as iterations) of every check in its own
+// workgroup, all at once — so that the sequential part (k_pairing) does ONE line product per iteration whatever S is.
 // Per workgroup: the 2 S sparse values (a Y + b X Z w + c Z^3 w^3; the pieces arrive as (X Z, Y, Z^3)), the S sparse x sparse
 // products, then a binary tree of general products over Fq2[w]/(w^6 - xi) — the same dot2 lanes and fold as k_pairing.
 #define PL_THREADS 192          // two general products per pass (72 lanes each)
-#define PL_MAX_PARTS 8
+#define PL_MAX_PARTS MSM_MAX_PARTS
+#define PL_MAX_EL (2 * PL_MAX_PARTS)   // sparse pairs per iteration: parts x (doubling, addition)
+struct PairIters { uint8_t first[PAIR_ITERS], cnt[PAIR_ITERS]; };   // iteration -> its lines in the context's tables
 struct PairLinesShared {
-    Coef el[2][PL_MAX_PARTS][6];                    // the tree's elements, ping-pong
+    Coef el0[PL_MAX_EL][6];                         // the tree's elements, ping-pong with u.el1
+    Fq2 prod[2][36];                                // partial products of the general products in flight
     union {
-        struct { Coef ev[2 * PL_MAX_PARTS][3]; Fq2 sp[PL_MAX_PARTS][9]; } l;   // line values (w^0, w^1, w^3) and the sparse products A_u * B_v at [3 u + v]
-        Fq2 prod[2][36];                            // partial products of the general products in flight
+        struct { Coef ev[2 * PL_MAX_EL][3]; Fq2 sp[PL_MAX_EL][9]; } l;   // line values (w^0, w^1, w^3) and the sparse products A_u * B_v at [3 u + v]
+        Coef el1[PL_MAX_EL][6];
     } u;
 };
-__global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ ready, uint32_t S, const LineCoeff* __restrict__ tab, Fq2* __restrict__ out) {
+__global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ ready, uint32_t S, const LineCoeff* __restrict__ tab, PairIters its, Fq2* __restrict__ out) {
     __shared__ PairLinesShared s;
-    const uint32_t step = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
-    // line l = 2 j + side at the point ready[(2 chk + side) S + j] = (X Z, Y, Z^3): a Y + b (X Z) w + c Z^3 w^3.  Lane (l, k, component).
-    for (uint32_t idx = t; idx < 2 * S * 6; idx += PL_THREADS) {
-        const uint32_t l = idx / 6, k = (idx % 6) >> 1, c = idx & 1u, j = l >> 1, side = l & 1u;
+    const uint32_t it = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
+    const uint32_t first = its.first[it], NP = S * its.cnt[it];   // sparse pair q = li * S + j: the lines (both sides) of piece j at line first + li
+    // line leaf l = 2 q + side at the point ready[(2 chk + side) S + j] = (X Z, Y, Z^3): a Y + b (X Z) w + c Z^3 w^3.  Lane (l, k, component).
+    for (uint32_t idx = t; idx < 2 * NP * 6; idx += PL_THREADS) {
+        const uint32_t l = idx / 6, k = (idx % 6) >> 1, c = idx & 1u, q = l >> 1, side = l & 1u, j = q % S, li = q / S;
         const G1J& P = ready[(size_t)(2 * chk + side) * S + j].p;
-        const LineCoeff& q = tab[(size_t)l * N_LINES + step];
-        const Fq2& co = k == 0 ? q.a : (k == 1 ? q.b : q.c);
+        const LineCoeff& lc = tab[(size_t)(2 * j + side) * N_LINES + first + li];
+        const Fq2& co = k == 0 ? lc.a : (k == 1 ? lc.b : lc.c);
         const Fq& f = k == 0 ? P.Y : (k == 1 ? P.X : P.Z);
         Fq r = Fq::mul_inl(c ? co.c1 : co.c0, f);
         if (P.is_identity()) r = (k == 0 && c == 0) ? Fq::one() : Fq::zero();   // an identity point contributes the line value 1
@@ -320,8 +335,8 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
         if (c) { e.c1 = r; e.n1 = r.neg(); } else e.c0 = r;
     }
     __syncthreads();
-    // the S sparse x sparse products, nine Fq2 products each: lane (j, u, v, coordinate), one dot2
-    for (uint32_t idx = t; idx < S * 18; idx += PL_THREADS) {
+    // the NP sparse x sparse products, nine Fq2 products each: lane (j, u, v, coordinate), one dot2
+    for (uint32_t idx = t; idx < NP * 18; idx += PL_THREADS) {
         const uint32_t j = idx / 18, pr = (idx % 18) >> 1, coord = idx & 1u;
         const Coef& a = s.u.l.ev[2 * j][pr / 3];
         const Coef& b = s.u.l.ev[2 * j + 1][pr % 3];
@@ -331,7 +346,7 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
     __syncthreads();
     // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4:
     // lane (j, coefficient k, kind re / im / -im): at most two entries, xi as integer weights, one from_wide
-    for (uint32_t idx = t; idx < S * 18; idx += PL_THREADS) {
+    for (uint32_t idx = t; idx < NP * 18; idx += PL_THREADS) {
         const uint32_t j = idx / 18, k = (idx % 18) / 3, kind = idx % 3;
         Fq r = Fq::zero();
         if (k < 5) {
@@ -352,12 +367,13 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
             }
             r = Fq::from_wide(acc);
         }
-        Coef& e = s.el[0][j][k];
+        Coef& e = s.el0[j][k];
         if (kind == 0) e.c0 = r; else if (kind == 1) e.c1 = r; else e.n1 = r;
     }
     __syncthreads();
     // binary tree of general products, two per pass
-    uint32_t m = S, cur = 0;
+    uint32_t m = NP, cur = 0;
+    auto el = [](uint32_t which) -> Coef (*)[6] { return which ? s.u.el1 : s.el0; };
     while (m > 1) {   // uniform
         const uint32_t np = m >> 1;
         for (uint32_t p0 = 0; p0 < np; p0 += 2) {
@@ -365,20 +381,20 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
             const bool on = slot < 2 && p < np;
             if (on) {
                 const uint32_t pr = lt >> 1, coord = lt & 1u, i = pr / 6, j = pr % 6;
-                const Coef& a = s.el[cur][2 * p][i];
-                const Coef& b = s.el[cur][2 * p + 1][j];
+                const Coef& a = el(cur)[2 * p][i];
+                const Coef& b = el(cur)[2 * p + 1][j];
                 const Fq r = Fq::dot2_inl(a.c0, coord ? b.c1 : b.c0, a.c1, coord ? b.c0 : b.n1);
-                if (coord) s.u.prod[slot][pr].c1 = r; else s.u.prod[slot][pr].c0 = r;
+                if (coord) s.prod[slot][pr].c1 = r; else s.prod[slot][pr].c0 = r;
             }
             __syncthreads();
-            if (on) fq12_fold(s.u.prod[slot], s.el[cur ^ 1][p], lt);
+            if (on) fq12_fold(s.prod[slot], el(cur ^ 1)[p], lt);
             __syncthreads();
         }
-        if ((m & 1u) && t < 6) s.el[cur ^ 1][np][t] = s.el[cur][m - 1][t];   // the odd one out moves up as it is
+        if ((m & 1u) && t < 6) el(cur ^ 1)[np][t] = el(cur)[m - 1][t];   // the odd one out moves up as it is
         __syncthreads();
         m = np + (m & 1u); cur ^= 1;
     }
-    if (t < 6) out[((size_t)chk * N_LINES + step) * 6 + t] = Fq2{s.el[cur][0][t].c0, s.el[cur][0][t].c1};
+    if (t < 6) out[((size_t)chk * PAIR_ITERS + it) * 6 + t] = Fq2{el(cur)[0][t].c0, el(cur)[0][t].c1};
 }
 
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok) {
@@ -391,14 +407,22 @@ int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_p
 
 int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_ready, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok) {
     if (!n) return 0;
-    if (!pd.prog || pd.n_ops > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
+    if (!pd.prog_merged || pd.n_ops_merged > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
     if (!parts || parts > PL_MAX_PARTS || !d_line_ws) { set_last_error("pairing: bad split"); return H2V_ERR_BAD_ARGUMENT; }
     const LineCoeff* tab = nullptr;
     int rc = pd.split_lines(shift, parts, &tab);
     if (rc) return rc;
     Fq2* lines = reinterpret_cast<Fq2*>(d_line_ws);
-    hipLaunchKernelGGL(k_pair_lines, dim3(N_LINES, n), dim3(PL_THREADS), 0, s, d_ready, parts, tab, lines);
-    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, (const Fq2*)lines, d_ok);
+    PairIters its;
+    uint32_t line = 0;
+    for (int i = 63; i >= 0; --i) {
+        const uint32_t cnt = 1u + (uint32_t)((ATE_LOW >> i) & 1);
+        its.first[63 - i] = (uint8_t)line; its.cnt[63 - i] = (uint8_t)cnt;
+        line += cnt;
+    }
+    for (int i = 64; i < PAIR_ITERS; ++i) { its.first[i] = (uint8_t)line++; its.cnt[i] = 1; }
+    hipLaunchKernelGGL(k_pair_lines, dim3(PAIR_ITERS, n), dim3(PL_THREADS), 0, s, d_ready, parts, tab, its, lines);
+    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog_merged, pd.n_ops_merged, (const Fq2*)lines, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

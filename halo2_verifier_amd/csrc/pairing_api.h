@@ -15,10 +15,10 @@ struct ParamsHost {
 bool params_from_bytes(const uint8_t* data, size_t len, int format, ParamsHost& out, std::string& err);
 
 PairingConsts pairing_consts_host();
-std::vector<uint32_t> pairing_program();
+std::vector<uint32_t> pairing_program(bool merged_lines);
 
 #define H2V_PAIRING_LINES 102   // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
-#define H2V_PAIRING_LINE_WS_BYTES ((size_t)H2V_PAIRING_LINES * 6 * sizeof(Fq2))   // per check: k_pair_lines' output
+#define H2V_PAIRING_LINE_WS_BYTES ((size_t)66 * 6 * sizeof(Fq2))   // per check: k_pair_lines' output, one Fq12 per Miller iteration (+ 2 corrections)
 
 struct PairingDevice {
     LineCoeff* l_sg2 = nullptr;  // line coefficients for s_g2
@@ -33,6 +33,8 @@ struct PairingDevice {
     PairingConsts* consts = nullptr;
     uint32_t* prog = nullptr;    // the pairing's operation table (pairing.hip: pairing_program)
     uint32_t n_ops = 0;
+    uint32_t* prog_merged = nullptr;   // the same with one line product per Miller iteration (checks over split accumulators)
+    uint32_t n_ops_merged = 0;
     int upload(const ParamsHost& p);
     void release();
 };

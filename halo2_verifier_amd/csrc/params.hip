@@ -128,10 +128,12 @@ int PairingDevice::upload(const ParamsHost& p) {
     H2V_HIP_CHECK(hipMemcpy(l_sg2, a.data(), sizeof(LineCoeff) * na, hipMemcpyHostToDevice));
     H2V_HIP_CHECK(hipMemcpy(l_ng2, b.data(), sizeof(LineCoeff) * na, hipMemcpyHostToDevice));
     H2V_HIP_CHECK(hipMemcpy(consts, &k, sizeof(PairingConsts), hipMemcpyHostToDevice));
-    const std::vector<uint32_t> ops = pairing_program();
-    n_ops = (uint32_t)ops.size();
+    const std::vector<uint32_t> ops = pairing_program(false), opsm = pairing_program(true);
+    n_ops = (uint32_t)ops.size(); n_ops_merged = (uint32_t)opsm.size();
     H2V_HIP_CHECK(hipMalloc(&prog, 4 * ops.size()));
     H2V_HIP_CHECK(hipMemcpy(prog, ops.data(), 4 * ops.size(), hipMemcpyHostToDevice));
+    H2V_HIP_CHECK(hipMalloc(&prog_merged, 4 * opsm.size()));
+    H2V_HIP_CHECK(hipMemcpy(prog_merged, opsm.data(), 4 * opsm.size(), hipMemcpyHostToDevice));
     return 0;
 }
 // 2^shift * q by the Miller loop's own doubling step (homogeneous projective), back to affine
@@ -171,6 +173,8 @@ void PairingDevice::release() {
     if (l_ng2) hipFree(l_ng2);
     if (consts) hipFree(consts);
     if (prog) hipFree(prog);
+    if (prog_merged) hipFree(prog_merged);
+    prog_merged = nullptr; n_ops_merged = 0;
     l_sg2 = l_ng2 = nullptr; consts = nullptr; prog = nullptr; n_ops = 0;
 }
 

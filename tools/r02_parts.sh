@@ -2,7 +2,7 @@
 # split-Horner parts sweep on the driver-shaped launch
 O="$GRAFT_REPO_ROOT/gpurun_out/${1:-r02_parts}"; mkdir -p "$O"
 cd "$GRAFT_REPO_ROOT"
-for P in 1 2 3 4 6 12; do
+for P in 4 6 8; do
   H2V_MSM_PARTS=$P timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-reupload-leg > "$O/b20_p$P.json" 2> "$O/b20_p$P.err" || { tail -5 "$O/b20_p$P.err"; exit 1; }
   python - "$O/b20_p$P.json" $P <<'PY'
 import json,sys
