@@ -22,13 +22,15 @@
 //                   lanes) and no bucket is ever too big for a lane (the top window of a 254-bit scalar is only a few bits
 //                   wide: its buckets collect hundreds of entries).  A bucket that lies inside one chunk is written
 //                   directly; the head and tail pieces of a chunk go to a side array and
-//      msm_fixup_classify / msm_fixup
-//                   a lane per bucket writes the identity for empty buckets and lists the buckets that straddle chunks;
-//                   a second, dense launch sums their pieces (buckets spread over more than 64 chunks — skewed inputs —
-//                   go to msm_fixup_heavy, one workgroup each)
-//   5. msm_window   one wave (four for more than 2048 buckets) per (problem, window): sum_b (b+1) * bucket[b] by per-lane
-//                   running sums over a slice of buckets, then a cross-lane butterfly (wave shuffles; LDS tree for four waves)
-//   6. msm_final    four lanes per problem: Horner over windows (c doublings + one add per window), every doubling split over the quad
+//                   the lane where such a bucket begins lists it (empty buckets are recognised by their count downstream);
+//      msm_fixup    a second, dense launch sums the listed buckets' pieces (buckets spread over more than 64 chunks — skewed
+//                   inputs — go to msm_fixup_heavy, one workgroup each)
+//   5. msm_window   sum_b (b+1) * bucket[b] per (problem, window) by per-lane running sums over a slice of buckets, then a cross-lane
+//                   butterfly (wave shuffles) or LDS tree: one wave per window, or two waves (four-wave workgroups of two windows,
+//                   so that every wave has a SIMD to itself), or four for more than 2048 buckets
+//   6. msm_final    four lanes per problem: Horner over windows (c doublings + one add per window), every doubling split over the quad;
+//      msm_final_parts / msm_combine_parts: the same Horner cut into pieces for a launch that ends in its own pairing checks
+//                   (MsmSplit): the checks take the pieces, the whole point is put together beside them
 //
 // Steps 1-3 are a hand-written counting sort (no atomics on points, no library sort); the only
 // atomics are 32-bit counters.  The order of additions inside a bucket depends on atomic
@@ -551,7 +553,8 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
     }
 }
 __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g) {
+                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g,
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists) {
     const uint32_t E = counts[nb + 1];
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
     // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
@@ -597,7 +600,18 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
         }
         b = b_next; bin_lo = lo_next; bin_hi = hi_next; qi = qn; q = q_next;
     }
-    if (!ok) msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E, g);  // redo the chunk with complete formulas
+    if (!ok) {
+        msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E, g);  // redo the chunk with complete formulas
+        b = msm_bin_of(g, offsets, chunk_hi - 1); bin_lo = msm_bin_start(g, offsets, b); bin_hi = bin_lo + counts[b];
+    }
+    // (b, bin_lo, bin_hi) is the chunk's last bucket.  If it goes on past the chunk and BEGINS here, this lane enters it in the fix-up's
+    // work lists (`lists` = the scatter cursors, free by now): buckets that straddle chunks from the front (their number in control[2]),
+    // buckets spread over >= MSM_FIXUP_SERIAL chunks from the back (control[0]).  A separate pass over all buckets to build the
+    // lists was 0.08 ms of a 20-step launch.
+    if (bin_hi > chunk_hi && bin_lo >= chunk_lo) {
+        if ((bin_hi - 1) / CH - lane >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&control[0], 1u)] = b;
+        else lists[atomicAdd(&control[2], 1u)] = b;
+    }
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
@@ -609,29 +623,8 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
     for (uint32_t i = i0 + 1; i <= i1; ++i) acc = g1_add(acc, msm_piece_src(partial, i, i0, off, CH)->p);
     *out = acc;
 }
-// After the scatter `cursor` is free and becomes two work lists: buckets that straddle chunks, from the front (their number
-// in counts[nb + 2]), and buckets spread over >= MSM_FIXUP_SERIAL chunks, from the back (counts[nb]).  Classifying first and
-// adding in a second, dense launch keeps the waves of the addition kernel full: only ~40 % of the buckets straddle.
-__global__ void __launch_bounds__(256) msm_fixup_classify(uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ lists,
-                                                          G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
-    const uint32_t CH = msm_chunk_len(counts[nb + 1]);
-    const uint32_t i0 = off / CH, i1 = cnt ? (off + cnt - 1) / CH : i0;   // i0 == i1: written whole by its chunk (or empty)
-    const bool heavy = i1 - i0 >= MSM_FIXUP_SERIAL, straddles = i1 != i0 && !heavy;
-    if (heavy) lists[nb - 1 - atomicAdd(&counts[nb], 1u)] = b;   // rare
-    // ~40 % of the bins straddle: one atomic per WAVE on the shared cursor instead of one per bin (200 000 atomics on one address
-    // were 0.08 ms of a 20-step launch)
-    const unsigned long long mask = __ballot(straddles);
-    if (mask) {
-        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&counts[nb + 2], (uint32_t)__popcll(mask));
-        base = (uint32_t)__shfl((int)base, (int)leader, 64);
-        if (straddles) lists[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = b;
-    }
-}
+// The work lists (buckets that straddle chunks) are built by msm_accumulate; the additions run in a second, dense launch that keeps
+// its waves full: only ~40 % of the buckets straddle.
 __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                                 const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,18 +675,23 @@ __device__ __noinline__ void g1_dbl_to(G1J* dst, const G1J* a) { const G1J x = *
 // lane live in LDS (dynamic: 3 x T points, + T for the four-wave tree): kept in private memory across the calls they cost
 // 0.35 GB of scratch write-backs per launch.
 // Empty buckets are recognised by their count: nobody writes an identity into their slots.
-__global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, const uint32_t* __restrict__ counts, G1JSlot* __restrict__ window_sums, MsmPlan p) {
+// A workgroup reduces `wpw` windows, T = blockDim.x / wpw lanes each (T a power of two, msm_window_threads).
+__global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, const uint32_t* __restrict__ counts, G1JSlot* __restrict__ window_sums, MsmPlan p,
+                                                              uint32_t n_windows, uint32_t wpw) {
     extern __shared__ G1J win_lds[];
-    const uint32_t w = blockIdx.x, q = blockIdx.y, t = threadIdx.x, T = blockDim.x;   // T: a power of two (msm_window_threads)
-    G1J* run = win_lds + t;
-    G1J* sum = win_lds + T + t;
-    G1J* scaled = win_lds + 2 * T + t;
-    G1J* red = win_lds + 3 * T;           // only allocated when T > 64
+    const uint32_t T = blockDim.x / wpw, sub = threadIdx.x / T, t = threadIdx.x % T;
+    const uint32_t widx = blockIdx.x * wpw + sub;          // (problem, window) = widx / windows, widx % windows
+    const bool live = widx < n_windows;
+    G1J* mine = win_lds + (size_t)sub * 3 * T;
+    G1J* run = mine + t;
+    G1J* sum = mine + T + t;
+    G1J* scaled = mine + 2 * T + t;
+    G1J* red = mine + 2 * T;              // the tree of T > 64 reuses the slots of `scaled` (each lane's own slot: dead by then)
     const uint32_t slice = (p.buckets + T - 1) / T;
-    const uint32_t lo = min(p.buckets, t * slice), hi = min(p.buckets, lo + slice);
+    const uint32_t lo = live ? min(p.buckets, t * slice) : 0, hi = live ? min(p.buckets, lo + slice) : 0;
     *run = G1J::identity(); *sum = G1J::identity();
-    const G1JSlot* bp = bucket_pts + ((size_t)q * p.windows + w) * p.buckets;
-    const uint32_t* cn = counts + ((size_t)q * p.windows + w) * p.buckets;
+    const G1JSlot* bp = bucket_pts + (size_t)widx * p.buckets;
+    const uint32_t* cn = counts + (size_t)widx * p.buckets;
     for (uint32_t b = hi; b > lo; --b) {
         if (cn[b - 1]) g1_add_to(run, run, &bp[b - 1].p);
         g1_add_to(sum, sum, run);
@@ -707,21 +705,21 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
         }
         g1_add_to(sum, sum, scaled);
     }
-    if (T <= 64) {
+    if (blockDim.x <= 64) {
         // a single wave: butterfly over the lanes with cross-lane moves (27 dwords per step), no barrier;
         // lanes beyond T hold the identity
         for (uint32_t d = 32; d > 0; d >>= 1) {
-            const G1J mine = *sum;
+            const G1J mine_sum = *sum;
             G1J other;
             uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&mine);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&mine_sum);
 #pragma unroll
             for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 64);
             if (t + d >= T) other = G1J::identity();
             *scaled = other;
             g1_add_to(sum, sum, scaled);
         }
-        if (t == 0) window_sums[(size_t)q * p.windows + w] = *sum;
+        if (t == 0) window_sums[widx] = *sum;
         return;
     }
     red[t] = *sum;
@@ -730,7 +728,7 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
         if (t < d) g1_add_to(&red[t], &red[t], &red[t + d]);
         __syncthreads();
     }
-    if (t == 0) window_sums[(size_t)q * p.windows + w] = red[0];
+    if (t == 0 && live) window_sums[widx] = red[0];
 }
 
 // ---- msm_final: Horner over the windows — c doublings and one addition per window, ~130 dependent group operations, nothing
@@ -870,16 +868,22 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     const size_t max_entries = total * 2 * p.windows;
     const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN);   // surplus workgroups return at once
     if (ws.profile) hipEventRecord(ws.ev_acc[0], s);
-    hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g);
+    hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor);
     if (ws.profile) { hipEventRecord(ws.ev_acc[1], s); ws.profile_recorded = true; }
-    hipLaunchKernelGGL(msm_fixup_classify, dim3((nb + 255) / 256), dim3(256), 0, s, ws.counts, ws.offsets, ws.cursor, ws.bucket_pts, nb, g);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {
-        const uint32_t T = msm_window_threads(p.buckets, p.windows * count);
-        const size_t win_lds = (size_t)(T > 64 ? 4 : 3) * T * sizeof(G1J);   // 20 KB for one wave, 108 KB for four
+        // Two-wave workgroups land on overlapping SIMD pairs when a CU holds two of them (measured: 0.57 ms for what one wave per
+        // window does in 0.48), so beyond 256 windows a workgroup is FOUR waves reducing two windows, two waves each: every wave
+        // has a SIMD of its own as long as the launch has at most one workgroup per CU.
+        const uint32_t nw = p.windows * count;
+        uint32_t T = msm_window_threads(p.buckets, nw), wpw = 1;
+        static const char* wpw_env = getenv("H2V_MSM_WIN_WPW");
+        if (T == 64 && p.buckets >= 256 && nw > 256 && nw <= 512) { T = 128; wpw = 2; }
+        if (wpw_env && T * (uint32_t)atoi(wpw_env) <= MSM_WIN_THREADS) wpw = (uint32_t)atoi(wpw_env);
+        const size_t win_lds = (size_t)3 * T * wpw * sizeof(G1J);   // 20 KB for one wave, 81 KB for four
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
-        hipLaunchKernelGGL(msm_window, dim3(p.windows, count), dim3(T), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p);
+        hipLaunchKernelGGL(msm_window, dim3((nw + wpw - 1) / wpw), dim3(T * wpw), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p, nw, wpw);
     }
     if (split && split->want_parts > 1 && p.windows > 1) {
         const uint32_t want = std::min<uint32_t>(split->want_parts, MSM_MAX_PARTS);
