@@ -98,6 +98,7 @@ struct h2v_batch {
     uint32_t* ok = nullptr;       // [groups]
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
     uint32_t* fold_failed = nullptr;  // [groups] failed proofs reported by the folded shards (h2v_batch_fold_check_enqueue)
+    uint8_t* results = nullptr; uint8_t* results_host = nullptr; size_t results_bytes = 0;   // ok / fold_failed / out_ident / out_bytes / status live in `results`
     h2v::MsmWorkspace ws;
     h2v::MsmSplit split;              // how the last launch left its accumulators to the pairing (parts == 0: whole points in acc)
     void* line_ws = nullptr; size_t line_ws_groups = 0;   // k_pair_lines' output, H2V_PAIRING_LINE_WS_BYTES per group

@@ -30,7 +30,6 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->inst, N * (size_t)pl.n_instance_values * 32))) return rc;
     if ((rc = dev_alloc(b->pts, N * pl.n_points + pl.n_shared))) return rc;
     if ((rc = dev_alloc(b->ycanon, N * pl.n_points * 32))) return rc;
-    if ((rc = dev_alloc(b->status, N))) return rc;
     if ((rc = dev_alloc(b->words, (size_t)words * N))) return rc;
     if ((rc = dev_alloc(b->chal, (size_t)pl.squeeze_at.size() * N))) return rc;
     if ((rc = dev_alloc(b->mult, N))) return rc;
@@ -41,10 +40,18 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->insteval, N * pl.inst_queries.size()))) return rc;
     if ((rc = dev_alloc(b->guard_scal, N * pl.guard_term_order.size() * 8))) return rc;
     if ((rc = dev_alloc(b->acc, 2 * G))) return rc;
-    if ((rc = dev_alloc(b->ok, G))) return rc;
-    if ((rc = dev_alloc(b->out_bytes, 128 * G))) return rc;
-    if ((rc = dev_alloc(b->out_ident, 2 * G))) return rc;
-    if ((rc = dev_alloc(b->fold_failed, G))) return rc;
+    // everything h2v_batch_finish reads back sits in ONE block, mirrored by one pinned host buffer: a single copy at the end of a
+    // launch (four separate copies into pageable memory were ~0.13 ms of a 20-step launch): [ok G][fold_failed G][out_ident 2 G]
+    // [out_bytes 128 G][status N]
+    b->results_bytes = 144 * G + 4 * N;
+    if ((rc = dev_alloc(b->results, b->results_bytes))) return rc;
+    if (b->results_host) { hipHostFree(b->results_host); b->results_host = nullptr; }
+    H2V_HIP_CHECK(hipHostMalloc((void**)&b->results_host, b->results_bytes ? b->results_bytes : 1, hipHostMallocDefault));
+    b->ok = reinterpret_cast<uint32_t*>(b->results);
+    b->fold_failed = b->ok + G;
+    b->out_ident = b->ok + 2 * G;
+    b->out_bytes = b->results + 16 * G;
+    b->status = reinterpret_cast<int*>(b->results + 144 * G);
     if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + G * pl.n_shared)), (uint32_t)(2 * G), (uint32_t)((N + G - 1) / G * pl.n_points + pl.n_shared)))) return rc;
     b->cap_plan_sig = sig;
     return 0;
@@ -220,15 +227,14 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     hipStream_t s = b->stream;
     const uint32_t n = b->n, G = b->groups, gs = n / G;
-    std::vector<int> st(n ? n : 1, 0);
-    std::vector<uint32_t> okv(G, 1), foldf(G, 0);
-    std::vector<uint8_t> outb(128 * (size_t)G, 0);
-    if (n) H2V_HIP_CHECK(hipMemcpyAsync(st.data(), b->status, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-    if (b->with_pairing) H2V_HIP_CHECK(hipMemcpyAsync(okv.data(), b->ok, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
-    H2V_HIP_CHECK(hipMemcpyAsync(outb.data(), b->out_bytes, 128 * (size_t)G, hipMemcpyDeviceToHost, s));
-    H2V_HIP_CHECK(hipMemcpyAsync(foldf.data(), b->fold_failed, 4 * (size_t)G, hipMemcpyDeviceToHost, s));
+    const size_t nbytes = 144 * (size_t)G + 4 * (size_t)n;
+    H2V_HIP_CHECK(hipMemcpyAsync(b->results_host, b->results, nbytes, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_last_error(std::string("h2v_batch_finish: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
+    const uint32_t* okv = reinterpret_cast<const uint32_t*>(b->results_host);
+    const uint32_t* foldf = okv + G;
+    const uint8_t* outb = b->results_host + 16 * (size_t)G;
+    const int* st = reinterpret_cast<const int*>(b->results_host + 144 * (size_t)G);
     if (b->profiling) {
         // events: 0 start, 1 after decompression, 2 after transcript + multipliers, 3 after Fr program, 4 after fold, 5 after MSMs, 6 after pairing
         float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t45 = 0, t56 = 0;
@@ -392,9 +398,10 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
-    hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->status); hipFree(b->words); hipFree(b->chal);
-    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc); hipFree(b->ok);
-    hipFree(b->out_bytes); hipFree(b->out_ident); hipFree(b->fold_failed); hipFree(b->line_ws);
+    hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->results); hipFree(b->words); hipFree(b->chal);
+    hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc);
+    hipFree(b->line_ws);
+    if (b->results_host) hipHostFree(b->results_host);
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     if (b->aux) { hipStreamSynchronize(b->aux); hipStreamDestroy(b->aux); }

@@ -57,7 +57,7 @@ struct MsmProblem {
         : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n1_ + n2), n1(n1_), scalars2(s2), bases2(b2) {}
 };
 #define MSM_MAX_PROBLEMS 1024     // per launch (a grouped batch: two channels per group; SingleStrategy: one group per proof)
-#define MSM_PROBLEM_CHUNK 16      // descriptors handed to the device per setter launch (kernel-argument space)
+#define MSM_PROBLEM_CHUNK 48      // descriptors handed to the device per setter launch (kernel-argument space)
 struct MsmProblemChunk { MsmProblem p[MSM_PROBLEM_CHUNK]; };
 struct MsmProblems { std::vector<MsmProblem> p; };
 
