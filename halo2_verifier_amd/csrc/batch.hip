@@ -148,11 +148,11 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
         if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(sm, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
         else if ((rc = multipliers_enqueue(sm, b->tail, b->n_tail, n, G, b->mult))) return rc;
+        H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, sm));  // the program writes only the slots the left channel uses
         H2V_HIP_CHECK(hipEventRecord(b->ev_join0, sm));
         H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join0, 0));   // joined before the Fr program reads them
     }
     mark();
-    if (n) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, s));  // the program writes only the slots the left channel uses
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
                b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval, b->guard_scal, (uint32_t)pl.guard_term_order.size()};
     if (n && pl.wide_instances) {
@@ -177,6 +177,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         for (uint32_t g = 0; g < G; ++g) {
             const size_t first = (size_t)g * gs * np;
             pr.p.push_back(MsmProblem(b->left_scal + first * 8, b->pts + first, b->acc + 2 * g, 8, 1, gs * np));
+            pr.p.back().nnz = gs * (uint32_t)pl.left_term_order.size();   // the program writes only these slots, the rest stay zero
             pr.p.push_back(MsmProblem(b->msm_scal + first * 8, b->pts + first, b->acc + 2 * g + 1, 8, 1, gs * np,
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
         }

@@ -51,6 +51,8 @@ struct MsmProblem {
     uint32_t n1;
     const uint32_t* scalars2; const G1A* bases2;
     uint32_t glv_off = 0;   // first record of this problem in the launch's GLV table (set by msm_enqueue_multi)
+    uint32_t nnz = 0;       // if non-zero: a promise that at most this many of the n scalars are non-zero (sizes msm_accumulate's grid; a broken
+                            // promise costs time, not correctness)
     MsmProblem() : scalars(nullptr), bases(nullptr), out(nullptr), sstride(8), bstride(1), n(0), n1(0), scalars2(nullptr), bases2(nullptr) {}
     MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n_) : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n_), n1(n_), scalars2(nullptr), bases2(nullptr) {}
     MsmProblem(const uint32_t* s, const G1A* b, G1J* o, uint32_t ss, uint32_t bs, uint32_t n1_, const uint32_t* s2, const G1A* b2, uint32_t n2)
@@ -65,7 +67,8 @@ struct MsmProblems { std::vector<MsmProblem> p; };
 // indices, and a 108-byte object that straddles lines costs partial-line writes on both (measured 2.5x the bytes)
 struct alignas(128) G1JSlot {
     G1J p;
-    __host__ __device__ G1JSlot& operator=(const G1J& v) { p = v; return *this; }
+    uint32_t pad[5];   // written with the point: a store that leaves part of a 32-byte sector untouched is a read-modify-write in memory
+    __host__ __device__ G1JSlot& operator=(const G1J& v) { p = v; for (int i = 0; i < 5; ++i) pad[i] = 0; return *this; }
     __host__ __device__ operator const G1J&() const { return p; }
 };
 

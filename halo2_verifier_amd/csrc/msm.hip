@@ -60,7 +60,17 @@ __host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E) {
     const uint32_t c = (uint32_t)(((uint64_t)E + (uint64_t)k * MSM_ACC_LANES_PER_ROUND - 1) / ((uint64_t)k * MSM_ACC_LANES_PER_ROUND));
     return c < MSM_CHUNK_MIN ? MSM_CHUNK_MIN : c;
 }
+// workgroups of msm_accumulate for at most `max_entries` list entries: whatever E <= max_entries the device finds, its chunk
+// lanes ceil(E / msm_chunk_len(E)) stay within k whole rounds, k = the rounds of the bound itself
+static inline uint32_t msm_accumulate_blocks(size_t max_entries) {
+    size_t lanes;
+    if (max_entries <= (size_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MIN) lanes = (max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
+    else lanes = (max_entries + (size_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX - 1) / ((size_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX) * MSM_ACC_LANES_PER_ROUND;
+    return (uint32_t)(((lanes + 63) / 64 + 1 + 7) / 8 * 8);
+}
 #define MSM_FIXUP_SERIAL 64u     // a bucket spread over more chunks than this is summed by a workgroup
+#define MSM_FIXUP_TEAM 3u        // ... over more than this, by a team of eight lanes (the rest: one lane per bucket)
+#define MSM_FIXUP_TEAM_BLOCKS 256u
 #define MSM_WIN_THREADS 256
 #define MSM_HEAVY_THREADS 256
 
@@ -120,9 +130,9 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
         cap_list = std::max(cap_list, terms * 2 * std::max(msm_plan(n, false).windows, msm_plan(n, true).windows));
         if (n == max_per_problem) break;
     }
-    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 3) * 4));
+    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 4) * 4));
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
-    H2V_HIP_CHECK(hipMalloc(&cursor, mb * 4));
+    H2V_HIP_CHECK(hipMalloc(&cursor, 2 * mb * 4));   // scatter cursors; then the fix-up's work lists (second half: the team list)
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
     H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1JSlot)));
@@ -431,7 +441,7 @@ __global__ void __launch_bounds__(1024) msm_seg_scan(const uint32_t* __restrict_
         if (t == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (t == 0) { seg_start[nseg] = carry; control[0] = 0; control[1] = carry; control[2] = 0; }
+    if (t == 0) { seg_start[nseg] = carry; control[0] = 0; control[1] = carry; control[2] = 0; control[3] = 0; }
 }
 
 // the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y) — split into the load and the fix-up so that
@@ -552,17 +562,9 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
         }
     }
 }
-__global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g,
-                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists) {
-    const uint32_t E = counts[nb + 1];
-    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
-    // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
-    // each) instead of all of them (15 MB per 16-step launch): the gathers hit in L2 instead of going out to the fabric.
-    const uint32_t CH = msm_chunk_len(E);
-    const uint32_t blocks = ((E + CH - 1) / CH + 63) / 64, per_xcd = (blocks + 7) / 8;
-    if (blockIdx.x / 8 >= per_xcd) return;
-    const uint32_t lane = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * 64 + threadIdx.x;
+__device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, const MsmSeg& g,
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, uint32_t E, uint32_t CH, uint32_t lane) {
     const uint32_t chunk_lo = lane * CH;
     if (chunk_lo >= E) return;
     const uint32_t chunk_hi = min(chunk_lo + CH, E);
@@ -606,12 +608,28 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
     }
     // (b, bin_lo, bin_hi) is the chunk's last bucket.  If it goes on past the chunk and BEGINS here, this lane enters it in the fix-up's
     // work lists (`lists` = the scatter cursors, free by now): buckets that straddle chunks from the front (their number in control[2]),
-    // buckets spread over >= MSM_FIXUP_SERIAL chunks from the back (control[0]).  A separate pass over all buckets to build the
+    // buckets spread over >= MSM_FIXUP_SERIAL chunks from the back (control[0]), the ones in between in the second half (control[3]).  A separate pass over all buckets to build the
     // lists was 0.08 ms of a 20-step launch.
     if (bin_hi > chunk_hi && bin_lo >= chunk_lo) {
-        if ((bin_hi - 1) / CH - lane >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&control[0], 1u)] = b;
+        const uint32_t span = (bin_hi - 1) / CH - lane;   // further chunks the bucket runs into
+        if (span >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&control[0], 1u)] = b;
+        else if (span >= MSM_FIXUP_TEAM) lists[nb + atomicAdd(&control[3], 1u)] = b;   // summed by a team of lanes
         else lists[atomicAdd(&control[2], 1u)] = b;
     }
+}
+__global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g,
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists) {
+    const uint32_t E = counts[nb + 1];
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
+    // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
+    // each) instead of all of them (15 MB per 16-step launch): the gathers hit in L2 instead of going out to the fabric.
+    const uint32_t CH = msm_chunk_len(E);
+    const uint32_t blocks = ((E + CH - 1) / CH + 63) / 64, per_xcd = (blocks + 7) / 8;
+    // The grid (a multiple of 8) covers the host's bound on the entry count (msm_accumulate_blocks); were there more entries than
+    // promised (MsmProblem::nnz), a workgroup takes several blocks of chunks — slower, never wrong.
+    for (uint32_t j = blockIdx.x / 8; j < per_xcd; j += gridDim.x / 8)
+        msm_accumulate_chunk(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, g, control, lists, E, CH, ((blockIdx.x % 8) * per_xcd + j) * 64 + threadIdx.x);
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
@@ -625,9 +643,37 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
 }
 // The work lists (buckets that straddle chunks) are built by msm_accumulate; the additions run in a second, dense launch that keeps
 // its waves full: only ~40 % of the buckets straddle.
+// Buckets that run over a few chunks (the top window's: a 7-bit digit, a few dozen buckets that take 1/64 of the entries each) are
+// rare but scattered through the list: one lane per bucket, every second wave had one of them and waited for its 8 .. 16 sequential
+// additions (0.13 - 0.45 ms for 0.03 ms of arithmetic).  They are summed by teams of eight lanes in the first workgroups of the launch.
+__device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
+                                            const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, const MsmSeg& g) {
+    const uint32_t n_team = counts[nb + 3], r = threadIdx.x & 7u;
+    const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+    // whole waves loop together (the shuffles below need all eight lanes of a team): the trip count is rounded up per wave
+    for (uint32_t m0 = blockIdx.x * 8; m0 < n_team; m0 += MSM_FIXUP_TEAM_BLOCKS * 8) {
+        const uint32_t m = m0 + (threadIdx.x >> 3);
+        const bool live = m < n_team;
+        const uint32_t b = live ? lists[nb + m] : 0;
+        const uint32_t cnt = live ? counts[b] : 0, off = live ? msm_bin_start(g, offsets, b) : 0;
+        const uint32_t i0 = off / CH, i1 = cnt ? (off + cnt - 1) / CH : i0;
+        G1J acc = G1J::identity();
+        if (live) for (uint32_t i = i0 + r; i <= i1; i += 8) acc = g1_add(acc, msm_piece_src(partial, i, i0, off, CH)->p);
+        for (uint32_t d = 4; d > 0; d >>= 1) {
+            G1J other;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
+#pragma unroll
+            for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 8);
+            acc = g1_add(acc, other);   // lanes r >= 8 - d add a neighbour's value they do not own: harmless, only r = 0 is kept
+        }
+        if (live && r == 0) bucket_pts[b] = acc;
+    }
+}
 __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                                 const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x < MSM_FIXUP_TEAM_BLOCKS) { msm_fixup_team(counts, offsets, partial, lists, bucket_pts, nb, g); return; }
+    const uint32_t k = (blockIdx.x - MSM_FIXUP_TEAM_BLOCKS) * blockDim.x + threadIdx.x;
     if (k >= counts[nb + 2]) return;
     const uint32_t b = lists[k];
     const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
@@ -678,6 +724,7 @@ __device__ __noinline__ void g1_dbl_to(G1J* dst, const G1J* a) { const G1J x = *
 // A workgroup reduces `wpw` windows, T = blockDim.x / wpw lanes each (T a power of two, msm_window_threads).
 __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, const uint32_t* __restrict__ counts, G1JSlot* __restrict__ window_sums, MsmPlan p,
                                                               uint32_t n_windows, uint32_t wpw) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     extern __shared__ G1J win_lds[];
     const uint32_t T = blockDim.x / wpw, sub = threadIdx.x / T, t = threadIdx.x % T;
     const uint32_t widx = blockIdx.x * wpw + sub;          // (problem, window) = widx / windows, widx % windows
@@ -777,6 +824,7 @@ __device__ __forceinline__ G1J msm_horner_quad(const G1JSlot* __restrict__ src, 
     return acc;
 }
 __global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = t >> 2, r = t & 3u;
     if (q >= count) return;   // whole quads
     G1J acc = G1J::identity();
@@ -790,6 +838,7 @@ __global__ void __launch_bounds__(64) msm_final(const G1JSlot* __restrict__ wind
 // a piece is (wpp - 1) c of them.  The full sum (the accumulator a caller can read back) is put together beside the pairing.
 __global__ void __launch_bounds__(64) msm_final_parts(const G1JSlot* __restrict__ window_sums, const MsmProblem* __restrict__ prs, uint32_t count, MsmPlan p,
                                                       uint32_t parts, uint32_t wpp, G1JSlot* __restrict__ out, G1JSlot* __restrict__ ready) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, quad = t >> 2, r = t & 3u;
     if (quad >= count * parts) return;   // whole quads
     const uint32_t q = quad / parts, j = quad % parts, lo = j * wpp, hi = min(p.windows, lo + wpp);
@@ -818,8 +867,8 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     const uint32_t count = (uint32_t)pr.p.size();
     if (count == 0) return 0;
     if (count > MSM_MAX_PROBLEMS || count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
-    uint32_t nmax = 0; size_t total = 0;
-    for (uint32_t q = 0; q < count; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; }
+    uint32_t nmax = 0; size_t total = 0, total_nz = 0;
+    for (uint32_t q = 0; q < count; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; total_nz += pr.p[q].nnz ? std::min(pr.p[q].nnz, pr.p[q].n) : pr.p[q].n; }
     uint32_t glv_next = 0;
     for (uint32_t q0 = 0; q0 < count; q0 += MSM_PROBLEM_CHUNK) {
         MsmProblemChunk ch;
@@ -850,7 +899,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
         hipLaunchKernelGGL(msm_seg_scan, dim3(1), dim3(1024), 0, s, ws.seg_total, p.windows * count, ws.seg_start, ws.counts + nb);
         g = MsmSeg{ws.seg_start, p.windows * count, p.buckets, stride};
     } else {
-    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 3) * 4, s));
+    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 4) * 4, s));
     H2V_HIP_CHECK(hipMemsetAsync(ws.seg_start, 0, 4, s));   // one segment that starts at 0
     const uint32_t tiles = (nmax + MSM_TILE - 1) / MSM_TILE;
     dim3 gt(8 * ((count + 7) / 8) * tiles);
@@ -864,13 +913,15 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, count, tiles, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
     g = MsmSeg{ws.seg_start, 1, nb, 0};
     }
-    // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers its upper bound
-    const size_t max_entries = total * 2 * p.windows;
-    const uint32_t chunks = (uint32_t)((max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN);   // surplus workgroups return at once
+    // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers the host's bound on it.
+    // Surplus workgroups are not free: the kernel holds exactly its occupancy in working workgroups (2 waves per SIMD), so the
+    // surplus is dispatched after they retire, ~7 ns each — the old bound (every term non-zero, shortest chunk) cost 9 500 empty
+    // workgroups, 0.07 ms, at the end of every 20-step launch.
+    const uint32_t acc_blocks = msm_accumulate_blocks(total_nz * 2 * p.windows);
     if (ws.profile) hipEventRecord(ws.ev_acc[0], s);
-    hipLaunchKernelGGL(msm_accumulate, dim3(((chunks + 63) / 64 + 7) / 8 * 8), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor);
+    hipLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor);
     if (ws.profile) { hipEventRecord(ws.ev_acc[1], s); ws.profile_recorded = true; }
-    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
+    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64 + MSM_FIXUP_TEAM_BLOCKS), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {
         // Two-wave workgroups land on overlapping SIMD pairs when a CU holds two of them (measured: 0.57 ms for what one wave per

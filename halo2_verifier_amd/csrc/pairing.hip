@@ -188,6 +188,7 @@ __device__ __forceinline__ void fq12_fold(const Fq2* prod, Coef* dst, uint32_t t
 __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
                                                           const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
                                                           const uint32_t* __restrict__ prog, uint32_t n_ops, const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     __shared__ PairShared s;
     const uint32_t chk = blockIdx.x, t = threadIdx.x;
     if (chk >= n) return;
@@ -319,6 +320,7 @@ struct PairLinesShared {
     } u;
 };
 __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ ready, uint32_t S, const LineCoeff* __restrict__ tab, PairIters its, Fq2* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     __shared__ PairLinesShared s;
     const uint32_t it = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
     const uint32_t first = its.first[it], NP = S * its.cnt[it];   // sparse pair q = li * S + j: the lines (both sides) of piece j at line first + li

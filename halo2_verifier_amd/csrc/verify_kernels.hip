@@ -452,6 +452,7 @@ struct SlotFile {
 };
 
 __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     extern __shared__ uint32_t frvm_lds[];
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n) return;
