@@ -1,0 +1,129 @@
+"""The pairing over SPLIT accumulators (csrc/msm.hip: msm_final_parts, csrc/pairing.hip: k_pair_lines).
+
+A launch that ends in its own pairing checks leaves every accumulator as `parts` points,
+    acc = sum_j 2^(shift j) piece_j,
+and checks  prod_j e(L_j, 2^(shift j) s_g2) e(R_j, -2^(shift j) g2) == 1  against tables of G2 multiples built on the host,
+while the whole points are put together beside the pairing.  Whatever the number of pieces (H2V_MSM_PARTS, read per launch;
+1 = the unsplit path), verdicts, per-proof statuses and the evaluated accumulator channels must be the oracle's, bit for
+bit — for accepted batches, for a batch whose pairing fails, with a rejected proof inside, for grouped launches, for one proof
+per check (SingleStrategy) and for both multi-open schemes (different window plans, i.e. different shifts)."""
+import os
+import random
+
+import pytest
+
+import circuits
+from circuits import R_MOD
+
+pytestmark = pytest.mark.gpu
+
+PARTS = [1, 2, 3, 4, 5, 6]
+
+
+class _parts:
+    def __init__(self, p):
+        self.p = p
+
+    def __enter__(self):
+        self.old = os.environ.get("H2V_MSM_PARTS")
+        os.environ["H2V_MSM_PARTS"] = str(self.p)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("H2V_MSM_PARTS", None)
+        else:
+            os.environ["H2V_MSM_PARTS"] = self.old
+
+
+@pytest.fixture(scope="module")
+def pool():
+    s = circuits.setup_vector_mul(8, 8)
+    P, I = circuits.prove_vector_mul_batch(s, 96, seed=777, threads=16)
+    yield s, P, I
+    s.free()
+
+
+def _ctx(s):
+    import halo2_verifier_amd as h2v
+    return h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes),
+                       multiopen=s.multiopen, transcript=s.transcript)
+
+
+def test_every_part_count_matches_the_oracle(pool):
+    s, P, I = pool
+    ctx = _ctx(s)
+    rnd = random.Random(5)
+    for n in (1, 2, 33, 96):
+        rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+        exp = circuits.oracle_verify_batch(s, P[:n], I[:n], rand)
+        assert exp[0] is True
+        for parts in PARTS:
+            with _parts(parts):
+                assert ctx.verify_batch(P[:n], I[:n], rand) == exp, (n, parts)
+    ctx.close()
+
+
+def test_failing_pairing_and_rejected_proof(pool):
+    s, P, I = pool
+    ctx = _ctx(s)
+    n = 24
+    rnd = random.Random(6)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    # a wrong public input: every proof well-formed, the pairing fails (tests/vector_mul.rs:329-330)
+    I_bad = list(I[:n]); I_bad[7] = [[circuits.le32(5)] + I[7][0][1:]]
+    exp_bad = circuits.oracle_verify_batch(s, P[:n], I_bad, rand)
+    assert exp_bad[0] is False and exp_bad[1] == [0] * n
+    # an undecodable opening point: that proof is rejected and leaves the accumulators, the pairing over the rest passes
+    P_rej = list(P[:n]); b = bytearray(P_rej[11]); b[-33] = 0xff; P_rej[11] = bytes(b)
+    exp_rej = circuits.oracle_verify_batch(s, P_rej, I[:n], rand)
+    assert exp_rej[0] is False and exp_rej[1][11] != 0
+    for parts in PARTS:
+        with _parts(parts):
+            assert ctx.verify_batch(P[:n], I_bad, rand) == exp_bad, parts
+            assert ctx.verify_batch(P_rej, I[:n], rand) == exp_rej, parts
+    ctx.close()
+
+
+def test_grouped_launch_and_single_strategy(pool):
+    import halo2_verifier_amd as h2v
+    s, P, I = pool
+    ctx = _ctx(s)
+    G, gs = 6, 16
+    n = G * gs
+    rnd = random.Random(7)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    I2 = list(I[:n]); I2[2 * gs + 1] = [[circuits.le32(9)] + I[2 * gs + 1][0][1:]]      # group 2's pairing fails
+    flat, inst = b"".join(P[:n]), b"".join(b"".join(col) for i in I2 for col in i)
+    results = []
+    for parts in (1, 3, 6):
+        with _parts(parts):
+            b = h2v.Batch(ctx, n, 8, groups=G)
+            b.upload(flat, 1024, inst, [8], b"".join(r.to_bytes(32, "little") for r in rand))
+            b.launch(with_pairing=True)
+            results.append(b.finish_groups())
+            b.close()
+            # one check per proof: every proof its own accumulator pair, its own pieces
+            assert ctx.verify_each(P[:20], I2[:20]) == [0] * 20
+            assert ctx.verify_each(P[2 * gs:2 * gs + 3], I2[2 * gs:2 * gs + 3]) == [0, -2, 0]
+    assert results[0] == results[1] == results[2]
+    ok, st, left, right = results[0]
+    assert ok == [True, True, False, True, True, True] and st == [0] * n
+    for g in (0, 2, 5):
+        sl = slice(g * gs, (g + 1) * gs)
+        assert circuits.oracle_verify_batch(s, P[sl], I2[sl], rand[sl]) == (ok[g], st[sl], left[g], right[g])
+    ctx.close()
+
+
+def test_gwc_plan_has_its_own_shift():
+    """GWC has more left-channel terms and a different largest problem, hence another window plan: other G2 multiples."""
+    s = circuits.setup_vector_mul(8, 7).set_options(circuits.GWC, circuits.KECCAK256)
+    P, I = circuits.prove_vector_mul_batch(s, 12, seed=31, threads=8)
+    ctx = _ctx(s)
+    rand = [random.Random(8).randrange(1, R_MOD) for _ in range(12)]
+    exp = circuits.oracle_verify_batch(s, P, I, rand)
+    assert exp[0] is True
+    for parts in (1, 2, 6):
+        with _parts(parts):
+            assert ctx.verify_batch(P, I, rand) == exp, parts
+    ctx.close()
+    s.free()
