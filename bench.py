@@ -392,7 +392,7 @@ def rank_main(args):
                        "proofs_per_gpu_per_step": B, "steps_per_launch": G, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "MSM stage (msm_count, prefix sum, msm_scatter, msm_accumulate, msm_fixup, msm_window, msm_final; both channels of every step of a launch)", "terms_per_launch": terms_total,
+                         "kernel": "MSM stage (msm_glv_prep, msm_sort_lds, msm_seg_scan, msm_accumulate, msm_fixup, msm_window, msm_final_parts; both channels of every step of a launch)", "terms_per_launch": terms_total,
                          "algorithmic_bytes_per_launch": 96 * terms_total,
                          "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if isolated else "HIP events on the launch's stream, inside the timed region (other launches in flight)",
                          "mean_stage_ms_timed_region": stages["msm"],
