@@ -51,6 +51,7 @@ struct MsmProblem {
     uint32_t n1;
     const uint32_t* scalars2; const G1A* bases2;
     uint32_t glv_off = 0;   // first record of this problem in the launch's GLV table (set by msm_enqueue_multi)
+    uint32_t sub_first = 0, sub_count = 0;   // set by msm_enqueue_multi when it cuts a large problem into sub-problems (their window sums are merged)
     uint32_t nnz = 0;       // if non-zero: a promise that at most this many of the n scalars are non-zero (sizes msm_accumulate's grid; a broken
                             // promise costs time, not correctness)
     MsmProblem() : scalars(nullptr), bases(nullptr), out(nullptr), sstride(8), bstride(1), n(0), n1(0), scalars2(nullptr), bases2(nullptr) {}
@@ -89,7 +90,11 @@ struct MsmWorkspace {
     G1JSlot* bucket_pts = nullptr;  // [problems * windows * buckets]
     G1JSlot* window_sums = nullptr; // [problems * windows]
     G1JSlot* pieces = nullptr;      // [2][problems * MSM_MAX_PARTS] partial Horner sums (MsmSplit): Jacobian, then line-ready
-    MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight
+    MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight (sub-problems when large problems are cut)
+    MsmProblem* parents = nullptr;   // [cap_parents] the caller's problems when they were cut
+    G1JSlot* merged_sums = nullptr;  // [cap_parents * 128] window sums of the caller's problems, merged over their sub-problems
+    const MsmProblem* final_problems = nullptr;   // whichever of the two the last launch's Horner wrote through
+    uint32_t cap_parents = 0;
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
     uint32_t* glv = nullptr;         // [cap_list / 2] signed window digits of the launch's terms, window-major per problem (LDS sort path)

@@ -111,38 +111,53 @@ MsmPlan msm_plan(uint32_t n, bool latency) {
 // a launch is planned for latency when all its problems together are a few thousand terms
 static inline bool msm_latency_bound(size_t total_terms) { return total_terms <= 4096; }
 
+// Large problems are cut into sub-problems of at most MSM_LDS_SORT_MAX_TERMS terms (msm_enqueue_multi): the workspace is sized for the
+// sub-problems, and for the uncut form too (knob H2V_MSM_NO_TERM_SPLIT).
+static inline uint32_t msm_subproblems(uint32_t n) { return n > MSM_LDS_SORT_MAX_TERMS ? (n + MSM_LDS_SORT_MAX_TERMS - 1) / MSM_LDS_SORT_MAX_TERMS : 1u; }
 int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_per_problem) {
     release();
-    cap_terms = max_terms; cap_problems = max_problems;
     if (!max_per_problem || max_per_problem > max_terms) max_per_problem = max_terms;
+    const uint32_t subs = msm_subproblems(max_per_problem);
+    cap_terms = max_terms; cap_parents = max_problems;
+    cap_problems = (uint32_t)std::min<size_t>((size_t)max_problems * subs, MSM_MAX_PROBLEMS);
+    if (cap_problems < max_problems) cap_problems = max_problems;
+    const uint32_t per_sub = subs > 1 ? MSM_LDS_SORT_MAX_TERMS : max_per_problem;   // a cut problem's pieces can be exactly the limit
+    // (problems, largest problem) of the two forms a launch can take
+    const uint32_t form_n[2] = {per_sub, max_per_problem}, form_q[2] = {cap_problems, max_problems};
     size_t mb = 0;
-    for (int lat = 0; lat < 2; ++lat) {
-        for (uint32_t n = 1; n <= max_per_problem; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n, lat != 0); mb = std::max(mb, (size_t)p.windows * p.buckets); }
-        MsmPlan p = msm_plan(max_per_problem, lat != 0); mb = std::max(mb, (size_t)p.windows * p.buckets);
-    }
-    mb *= max_problems;
-    cap_buckets = mb;
-    // list entries: 2 GLV halves x windows per term, for the plan of the largest problem of a launch
     cap_list = 0;
-    for (uint32_t n = 1;; n = n < 16 ? n + 1 : n + n / 8) {
-        if (n > max_per_problem) n = max_per_problem;
-        size_t terms = std::min<size_t>(max_terms, (size_t)n * max_problems);
-        cap_list = std::max(cap_list, terms * 2 * std::max(msm_plan(n, false).windows, msm_plan(n, true).windows));
-        if (n == max_per_problem) break;
+    for (int f = 0; f < 2; ++f) {
+        size_t fb = 0;
+        for (int lat = 0; lat < 2; ++lat) {
+            for (uint32_t n = 1; n <= form_n[f]; n = n < 16 ? n + 1 : n + n / 8) { MsmPlan p = msm_plan(n, lat != 0); fb = std::max(fb, (size_t)p.windows * p.buckets); }
+            MsmPlan p = msm_plan(form_n[f], lat != 0); fb = std::max(fb, (size_t)p.windows * p.buckets);
+        }
+        mb = std::max(mb, fb * form_q[f]);
+        // list entries: 2 GLV halves x windows per term (segment-addressed: every problem owns 2 * nmax entries per window), for the plan of the largest problem of a launch
+        for (uint32_t n = 1;; n = n < 16 ? n + 1 : n + n / 8) {
+            if (n > form_n[f]) n = form_n[f];
+            // (the LDS sort gives every problem 2 * nmax list slots per window: problems x largest problem, not the term total)
+            size_t terms = n <= MSM_LDS_SORT_MAX_TERMS ? (size_t)n * form_q[f] : std::min<size_t>((size_t)max_terms, (size_t)n * form_q[f]);
+            cap_list = std::max(cap_list, terms * 2 * std::max(msm_plan(n, false).windows, msm_plan(n, true).windows));
+            if (n == form_n[f]) break;
+        }
     }
+    cap_buckets = mb;
     H2V_HIP_CHECK(hipMalloc(&counts, (mb + 4) * 4));
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&cursor, 2 * mb * 4));   // scatter cursors; then the fix-up's work lists (second half: the team list)
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
     H2V_HIP_CHECK(hipMalloc(&bucket_pts, mb * sizeof(G1JSlot)));
-    H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * max_problems * sizeof(G1JSlot)));
-    H2V_HIP_CHECK(hipMalloc(&pieces, (size_t)2 * MSM_MAX_PARTS * max_problems * sizeof(G1JSlot)));
-    H2V_HIP_CHECK(hipMalloc(&problems, (size_t)max_problems * sizeof(MsmProblem)));
+    H2V_HIP_CHECK(hipMalloc(&window_sums, (size_t)128 * cap_problems * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&merged_sums, (size_t)128 * cap_parents * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&pieces, (size_t)2 * MSM_MAX_PARTS * cap_problems * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&problems, (size_t)cap_problems * sizeof(MsmProblem)));
+    H2V_HIP_CHECK(hipMalloc(&parents, (size_t)cap_parents * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&glv, (cap_list / 2 + 1) * 4));   // digit table: one word per (term, window)
-    H2V_HIP_CHECK(hipMalloc(&seg_total, ((size_t)128 * max_problems + 2) * 4));
-    H2V_HIP_CHECK(hipMalloc(&seg_start, ((size_t)128 * max_problems + 2) * 4));
+    H2V_HIP_CHECK(hipMalloc(&seg_total, ((size_t)128 * cap_problems + 2) * 4));
+    H2V_HIP_CHECK(hipMalloc(&seg_start, ((size_t)128 * cap_problems + 2) * 4));
     for (int i = 0; i < 2; ++i) if (!ev_acc[i]) H2V_HIP_CHECK(hipEventCreate(&ev_acc[i]));
     return 0;
 }
@@ -156,6 +171,9 @@ void MsmWorkspace::release() {
     if (pieces) hipFree(pieces);
     pieces = nullptr;
     if (problems) hipFree(problems);
+    if (parents) hipFree(parents);
+    if (merged_sums) hipFree(merged_sums);
+    parents = nullptr; merged_sums = nullptr; final_problems = nullptr; cap_parents = 0;
     if (block_sums) hipFree(block_sums);
     if (partial) hipFree(partial);
     if (glv) hipFree(glv);
@@ -856,26 +874,94 @@ __global__ void __launch_bounds__(64) msm_combine_parts(const G1JSlot* __restric
     if (r == 0) *prs[q].out = acc;
 }
 
+// window sums of a caller's problem = the sums of its sub-problems' window sums, window by window (the same weights): a team of
+// eight lanes per (problem, window)
+__global__ void __launch_bounds__(64) msm_merge_windows(const G1JSlot* __restrict__ sub_sums, const MsmProblem* __restrict__ parents, uint32_t n_parents, uint32_t windows,
+                                                        G1JSlot* __restrict__ merged) {
+    const uint32_t team = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, r = threadIdx.x & 7u;
+    const bool live = team < n_parents * windows;
+    const uint32_t q = live ? team / windows : 0, w = live ? team % windows : 0;
+    const uint32_t first = parents[q].sub_first, cnt = live ? parents[q].sub_count : 0;
+    G1J acc = G1J::identity();
+    for (uint32_t k = r; k < cnt; k += 8) acc = g1_add(acc, sub_sums[(size_t)(first + k) * windows + w].p);
+    for (uint32_t d = 4; d > 0; d >>= 1) {
+        G1J other;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 8);
+        acc = g1_add(acc, other);   // lanes r >= 8 - d add a value they do not own: only r = 0 is kept
+    }
+    if (live && r == 0) merged[(size_t)q * windows + w] = acc;
+}
+
 // descriptors travel as kernel arguments, a chunk at a time: no host staging buffer whose lifetime the caller would have to manage
 __global__ void msm_set_problems(MsmProblemChunk ch, uint32_t count, MsmProblem* __restrict__ dst) {
     uint32_t i = threadIdx.x;
     if (i < count) dst[i] = ch.p[i];
 }
 
-int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split) {
-    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; split->ready = nullptr; }
-    const uint32_t count = (uint32_t)pr.p.size();
-    if (count == 0) return 0;
-    if (count > MSM_MAX_PROBLEMS || count > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
-    uint32_t nmax = 0; size_t total = 0, total_nz = 0;
-    for (uint32_t q = 0; q < count; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; total_nz += pr.p[q].nnz ? std::min(pr.p[q].nnz, pr.p[q].n) : pr.p[q].n; }
+// terms [first, first + len) of a problem as a problem of its own (no output of its own)
+static MsmProblem msm_problem_slice(const MsmProblem& q, uint32_t first, uint32_t len) {
+    MsmProblem r = q;
+    r.out = nullptr; r.n = len; r.nnz = 0; r.sub_first = 0; r.sub_count = 0;
+    if (first < q.n1) {
+        r.scalars = q.scalars + (size_t)q.sstride * first; r.bases = q.bases + (size_t)q.bstride * first;
+        r.n1 = std::min(q.n1 - first, len);
+    } else {
+        r.scalars = q.scalars2 + (size_t)q.sstride * (first - q.n1); r.bases = q.bases2 + (size_t)q.bstride * (first - q.n1);
+        r.n1 = len; r.scalars2 = nullptr; r.bases2 = nullptr;
+    }
+    return r;
+}
+static void msm_upload_problems(hipStream_t s, const std::vector<MsmProblem>& v, bool assign_glv, MsmProblem* dst) {
     uint32_t glv_next = 0;
+    const uint32_t count = (uint32_t)v.size();
     for (uint32_t q0 = 0; q0 < count; q0 += MSM_PROBLEM_CHUNK) {
         MsmProblemChunk ch;
         uint32_t k = std::min<uint32_t>(MSM_PROBLEM_CHUNK, count - q0);
-        for (uint32_t i = 0; i < k; ++i) { ch.p[i] = pr.p[q0 + i]; ch.p[i].glv_off = glv_next; glv_next += pr.p[q0 + i].n; }
-        hipLaunchKernelGGL(msm_set_problems, dim3(1), dim3(64), 0, s, ch, k, ws.problems + q0);
+        for (uint32_t i = 0; i < k; ++i) { ch.p[i] = v[q0 + i]; if (assign_glv) { ch.p[i].glv_off = glv_next; glv_next += v[q0 + i].n; } }
+        hipLaunchKernelGGL(msm_set_problems, dim3(1), dim3(64), 0, s, ch, k, dst + q0);
     }
+}
+
+int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split) {
+    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; split->ready = nullptr; }
+    const uint32_t n_callers = (uint32_t)pr.p.size();
+    if (n_callers == 0) return 0;
+    if (n_callers > MSM_MAX_PROBLEMS || n_callers > std::max(ws.cap_problems, ws.cap_parents)) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
+    uint32_t nmax = 0; size_t total = 0, total_nz = 0;
+    for (uint32_t q = 0; q < n_callers; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; total_nz += pr.p[q].nnz ? std::min(pr.p[q].nnz, pr.p[q].n) : pr.p[q].n; }
+    // A problem too large for the per-window LDS sort is cut into equal sub-problems that are not: the launch then looks like a
+    // grouped batch (LDS sort, short buckets, many narrow window reductions side by side) — for one 8192-proof batch the uncut form
+    // spent 0.77 ms in the global counting sort, 0.59 in the fix-up and 0.52 in two 4096-bucket window reductions.  The window sums
+    // of a problem's sub-problems are added up (msm_merge_windows) before the Horner.
+    std::vector<MsmProblem> launch_p, parents_p;
+    bool cut = false;
+    if (nmax > MSM_LDS_SORT_MAX_TERMS && !getenv("H2V_MSM_NO_TERM_SPLIT")) {
+        size_t subs = 0;
+        for (uint32_t q = 0; q < n_callers; ++q) subs += msm_subproblems(pr.p[q].n);
+        cut = subs <= ws.cap_problems && subs <= MSM_MAX_PROBLEMS && n_callers <= ws.cap_parents;
+    }
+    if (cut) {
+        for (uint32_t q = 0; q < n_callers; ++q) {
+            const MsmProblem& c = pr.p[q];
+            const uint32_t k = msm_subproblems(c.n), per = (c.n + k - 1) / k;
+            MsmProblem parent = c;
+            parent.sub_first = (uint32_t)launch_p.size(); parent.sub_count = k;
+            for (uint32_t i = 0; i < k; ++i) { const uint32_t first = std::min(c.n, i * per); launch_p.push_back(msm_problem_slice(c, first, std::min(per, c.n - first))); }
+            parents_p.push_back(parent);
+        }
+        nmax = 0;
+        for (const MsmProblem& q : launch_p) nmax = std::max(nmax, q.n);
+        msm_upload_problems(s, parents_p, false, ws.parents);
+    } else {
+        if (n_callers > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
+        launch_p = pr.p;
+    }
+    const uint32_t count = (uint32_t)launch_p.size();
+    msm_upload_problems(s, launch_p, true, ws.problems);
+    ws.final_problems = cut ? ws.parents : ws.problems;
     if (nmax == 0) {
         hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, MsmPlan{0, 2, 0, 3});
         H2V_HIP_CHECK(hipGetLastError());
@@ -936,20 +1022,25 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
         hipLaunchKernelGGL(msm_window, dim3((nw + wpw - 1) / wpw), dim3(T * wpw), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p, nw, wpw);
     }
+    const G1JSlot* sums = ws.window_sums;
+    if (cut) {
+        hipLaunchKernelGGL(msm_merge_windows, dim3((8 * n_callers * p.windows + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.parents, n_callers, p.windows, ws.merged_sums);
+        sums = ws.merged_sums;
+    }
     if (split && split->want_parts > 1 && p.windows > 1) {
         const uint32_t want = std::min<uint32_t>(split->want_parts, MSM_MAX_PARTS);
         const uint32_t wpp = (p.windows + want - 1) / want, parts = (p.windows + wpp - 1) / wpp;
-        hipLaunchKernelGGL(msm_final_parts, dim3((4 * count * parts + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p, parts, wpp, ws.pieces, ws.pieces + (size_t)MSM_MAX_PARTS * ws.cap_problems);
-        split->parts = parts; split->shift = p.c * wpp; split->count = count; split->pts = ws.pieces; split->ready = ws.pieces + (size_t)MSM_MAX_PARTS * ws.cap_problems;
+        hipLaunchKernelGGL(msm_final_parts, dim3((4 * n_callers * parts + 63) / 64), dim3(64), 0, s, sums, ws.final_problems, n_callers, p, parts, wpp, ws.pieces, ws.pieces + (size_t)MSM_MAX_PARTS * ws.cap_problems);
+        split->parts = parts; split->shift = p.c * wpp; split->count = n_callers; split->pts = ws.pieces; split->ready = ws.pieces + (size_t)MSM_MAX_PARTS * ws.cap_problems;
     } else {
-        hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, p);
+        hipLaunchKernelGGL(msm_final, dim3((4 * n_callers + 63) / 64), dim3(64), 0, s, sums, ws.final_problems, n_callers, p);
     }
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp) {
     if (!sp.parts) return 0;
-    hipLaunchKernelGGL(msm_combine_parts, dim3((4 * sp.count + 63) / 64), dim3(64), 0, s, sp.pts, ws.problems, sp.count, sp.parts, sp.shift);
+    hipLaunchKernelGGL(msm_combine_parts, dim3((4 * sp.count + 63) / 64), dim3(64), 0, s, sp.pts, ws.final_problems, sp.count, sp.parts, sp.shift);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
