@@ -46,6 +46,34 @@ def test_msm_matches_oracle(ctx, srs, oracle, n):
     assert ctx.msm_g1(scalars, bases) == oracle_lib.g1_msm(oracle, scalars, bases)
 
 
+@pytest.mark.parametrize("n", [16384, 16385, 40000])
+def test_msm_large_problem_is_cut(ctx, srs, oracle, n, monkeypatch):
+    """More terms than one per-window LDS sort takes (16 384): the problem is cut into sub-problems whose window sums are merged
+    (csrc/msm.hip: msm_merge_windows).  Same bytes as the oracle, and as the uncut form (global counting sort)."""
+    rnd = random.Random(7000 + n)
+    pts = [g1_xy(p) for p in srs.g]
+    scalars = [rnd.randrange(R_MOD) for _ in range(n)]
+    scalars[5] = 0
+    scalars[n - 1] = R_MOD - 1
+    scalars[16383] = 1
+    bases = [pts[rnd.randrange(srs.n)] for _ in range(n)]
+    bases[9] = bytes(64)
+    exp = oracle_lib.g1_msm(oracle, scalars, bases)
+    assert ctx.msm_g1(scalars, bases) == exp
+    monkeypatch.setenv("H2V_MSM_NO_TERM_SPLIT", "1")
+    assert ctx.msm_g1(scalars, bases) == exp
+
+
+def test_msm_large_skewed_problem(ctx, srs, oracle):
+    """A cut problem whose sub-problems are all one bucket per window (workgroup fix-up inside every sub-problem)"""
+    rnd = random.Random(8)
+    n = 33000
+    pts = [g1_xy(p) for p in srs.g]
+    k = rnd.randrange(R_MOD)
+    scalars, bases = [k] * n, [pts[rnd.randrange(srs.n)] for _ in range(n)]
+    assert ctx.msm_g1(scalars, bases) == oracle_lib.g1_msm(oracle, scalars, bases)
+
+
 @pytest.mark.parametrize("kind", ["one_scalar", "one_base", "same_term", "two_values", "small_scalars"])
 def test_msm_skewed_inputs(ctx, srs, oracle, kind):
     """Inputs that defeat the 'random scalars' assumptions of the bucket method: one bucket per window holds every
