@@ -128,6 +128,115 @@ std::vector<uint32_t> pairing_program(bool merged) {
     return p;
 }
 
+// ---- The same check as TWO operation streams run side by side by two groups of two waves (k_pairing2; checks over split
+// accumulators, i.e. the latency-critical ones).  A pairing is a chain, but its long stretches are Horner schemes in the exponent and
+// can be cut like the MSM's:
+//   Miller loop   f = prod_i L_i^(2^(63 - i)): group A runs iterations 0 .. 21 and then squares its value 42 more times, group B runs
+//                 iterations 22 .. 63 and the two Frobenius corrections, one product joins them: 86 steps instead of 130;
+//   x-powers      a^x = (a^hi)^(2^h) a^lo over the signed-window digits of x: A does the high digits and the h squarings, B the low
+//                 digits; the table of odd powers is built by both (a^4 = (a^2)^2 beside a^3, a^5 = a a^4 beside a^7 = a^3 a^4);
+//   the tail of the hard part pairs what is independent (y9 | y10, y12 | y11, ...).
+// Both groups step together (two barriers per step); a step's two operations never write, or write and read, the same register.
+// One step = uint2 (operation of A, operation of B), 0 = nothing to do.
+#define PAIR2_REGS 20
+#define PAIR2_MAX_STEPS 448
+std::vector<uint32_t> pairing_program2() {
+    std::vector<uint32_t> A, B;
+    enum { FA = 0, FB = 1, R = 2, T0 = 3, T1 = 4, T2 = 5, T3 = 6, T4 = 7, T5 = 8, T6 = 9, TAB = 10, D2 = 18 };
+    auto sync = [&]() { while (A.size() < B.size()) A.push_back(0); while (B.size() < A.size()) B.push_back(0); };
+    auto a1 = [&](uint32_t w) { sync(); A.push_back(w); B.push_back(0); };                 // a step of A alone
+    auto ab = [&](uint32_t wa, uint32_t wb) { sync(); A.push_back(wa); B.push_back(wb); };  // a step of both
+    auto SQR = [](uint32_t d, uint32_t a) { return pair_op(P_SQR, d, a, 0); };
+    auto MUL = [](uint32_t d, uint32_t a, uint32_t b) { return pair_op(P_MUL, d, a, b); };
+    auto MULL = [](uint32_t d, uint32_t a, uint32_t l) { return pair_op(P_MULL, d, a, l); };
+    auto CONJ = [](uint32_t d, uint32_t a) { return pair_op(P_CONJ, d, a, 0); };
+    auto FROB = [](uint32_t d, uint32_t a) { return pair_op(P_FROB, d, a, 0); };
+    auto COPY = [](uint32_t d, uint32_t a) { return pair_op(P_COPY, d, a, 0); };
+    // Miller loop over the merged line table (entry i: iteration i; 64, 65: the Frobenius corrections); FA = FB = 1 at the start
+    const int K = 22;
+    for (int i = 0; i < K; ++i) { if (i) A.push_back(SQR(FA, FA)); A.push_back(MULL(FA, FA, (uint32_t)i)); }
+    for (int i = K; i < 64; ++i) A.push_back(SQR(FA, FA));
+    for (int i = K; i < 64; ++i) { if (i > K) B.push_back(SQR(FB, FB)); B.push_back(MULL(FB, FB, (uint32_t)i)); }
+    B.push_back(MULL(FB, FB, 64)); B.push_back(MULL(FB, FB, 65));
+    a1(MUL(FA, FA, FB));
+    // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
+    const uint32_t F = FA;
+    a1(CONJ(T1, F));                       // conj(f) = f^(p^6)
+    a1(MUL(T2, F, T1));                    // N = f conj(f), in Fq6 (even powers of w)
+    a1(FROB(T3, T2)); a1(FROB(T3, T3));    // N^(p^2)
+    a1(FROB(T4, T3)); a1(FROB(T4, T4));    // N^(p^4)
+    a1(MUL(T3, T3, T4));                   // T = N^(p^2) N^(p^4)
+    a1(MUL(T4, T2, T3));                   // Norm(N) = N T, in Fq2 (coefficient 0)
+    a1(pair_op(P_INV2, T4, T4, 0));
+    a1(MUL(T3, T3, T4));                   // N^-1
+    a1(MUL(T0, T1, T3));                   // f^-1
+    a1(MUL(R, T1, T0));                    // f^(p^6 - 1)
+    a1(FROB(T0, R)); a1(FROB(T0, T0));
+    a1(MUL(R, T0, R));                     // ^(p^2 + 1)
+    // d = a^BN_X for a in the cyclotomic subgroup, d != a
+    std::vector<int> dig;   // width-4 non-adjacent form of x, least significant first
+    for (unsigned long long n = BN_X; n;) {
+        int z = 0;
+        if (n & 1) { z = (int)(n & 15); if (z >= 8) z -= 16; n -= (unsigned long long)(long long)z; }
+        dig.push_back(z);
+        n >>= 1;
+    }
+    auto tab = [&](int z) { return (uint32_t)(TAB + 2 * ((z < 0 ? -z : z) >> 1) + (z < 0 ? 1 : 0)); };
+    // digits [lo, hi) of x applied to register d by square-and-multiply, `extra` squarings behind them
+    auto chain = [&](std::vector<uint32_t>& col, uint32_t d, size_t lo, size_t hi, size_t extra) {
+        bool started = false;
+        for (size_t i = hi; i-- > lo;) {
+            if (started) col.push_back(SQR(d, d));
+            if (!dig[i]) continue;
+            if (started) col.push_back(MUL(d, d, tab(dig[i]))); else { col.push_back(COPY(d, tab(dig[i]))); started = true; }
+        }
+        for (size_t i = 0; i < extra; ++i) col.push_back(SQR(d, d));
+    };
+    // the cut that makes the longer of the two streams shortest; the low part must not be empty (x is odd: digit 0 is not zero)
+    size_t cut = 1, best = ~(size_t)0;
+    for (size_t h = 1; h + 1 < dig.size(); ++h) {
+        if (!dig[dig.size() - 1]) break;
+        std::vector<uint32_t> ca, cb;
+        chain(ca, 0, h, dig.size(), h); chain(cb, 0, 0, h, 0);
+        const size_t len = std::max(ca.size(), cb.size());
+        if (len < best) { best = len; cut = h; }
+    }
+    auto pow_x = [&](uint32_t d, uint32_t a) {
+        ab(COPY(TAB, a), SQR(D2, a));                        // a                | a^2
+        ab(MUL(TAB + 2, TAB, D2), SQR(d, D2));               // a^3              | a^4   (d is free until its chain starts)
+        ab(MUL(TAB + 4, TAB, d), MUL(TAB + 6, TAB + 2, d));  // a^5 = a a^4      | a^7 = a^3 a^4
+        ab(CONJ(TAB + 1, TAB), CONJ(TAB + 3, TAB + 2));
+        ab(CONJ(TAB + 5, TAB + 4), CONJ(TAB + 7, TAB + 6));
+        sync();
+        chain(A, d, cut, dig.size(), cut);                   // (a^hi)^(2^cut)
+        chain(B, D2, 0, cut, 0);                             // a^lo
+        a1(MUL(d, d, D2));
+    };
+    const uint32_t y0 = T0, y1 = T1, y3 = T2, y4 = T3, y6 = T4, u = T5, v = T6;
+    pow_x(y0, R); a1(CONJ(y0, y0));        // y0 = r^-x
+    a1(SQR(y1, y0));                       // y1 = y0^2
+    a1(SQR(u, y1));                        // y2 = y1^2
+    a1(MUL(y3, u, y1));                    // y3 = y2 y1
+    pow_x(y4, y3); a1(CONJ(y4, y4));       // y4 = y3^-x
+    a1(SQR(u, y4));                        // y5 = y4^2
+    pow_x(y6, u);                          // (the single-stream table conjugates y6 twice here: y5^-x and back)
+    a1(CONJ(y3, y3));
+    a1(MUL(u, y6, y4));                    // y7 = y6 y4
+    a1(MUL(u, u, y3));                     // y8 = y7 y3            (u = y8)
+    ab(MUL(v, u, y1), MUL(y0, u, y4));     // y9 = y8 y1 (v)        | y10 = y8 y4
+    ab(FROB(y1, v), MUL(y0, y0, R));       // y12 = y9^p            | y11 = y10 r
+    ab(MUL(y0, y1, y0), FROB(u, u));       // y13 = y12 y11         | y8^p
+    ab(CONJ(y1, R), FROB(u, u));           // conj(r)               | y8^(p^2)
+    ab(MUL(y1, y1, v), MUL(y0, u, y0));    // conj(r) y9            | y14 = y8^(p^2) y13
+    a1(FROB(y1, y1)); a1(FROB(y1, y1)); a1(FROB(y1, y1));   // y15
+    a1(MUL(y0, y1, y0));                   // y16
+    a1(pair_op(P_CHECK, 0, y0, 0));
+    sync();
+    std::vector<uint32_t> steps;
+    for (size_t i = 0; i < A.size(); ++i) { steps.push_back(A[i]); steps.push_back(B[i]); }
+    return steps;
+}
+
 struct Coef { Fq c0, c1, n1; };   // an Fq2 coefficient and the negated imaginary part: n1 = -c1
 struct alignas(16) PairShared {
     Fq2 line[N_LINES][6];         // per Miller step: the product of the step's line values, coefficients of w^0 .. w^5 (two lines: w^5 is zero)
@@ -185,6 +294,72 @@ __device__ __forceinline__ void fq12_fold(const Fq2* prod, Coef* dst, uint32_t t
     }
 }
 
+// ---- the two kinds of steps of the operation table, shared by k_pairing (one operation per step) and k_pairing2 (two)
+// products: one dot2 per lane t of the 128 that execute the operation; line = the Miller-line table, reg = the register file
+__device__ __forceinline__ void pair_products(uint32_t op, uint32_t ra, uint32_t rb, const Fq2 (*line)[6], const Coef (*reg)[6], Fq2* prod, uint32_t t) {
+    const uint32_t pr = t >> 1, coord = t & 1u;
+    uint32_t i = 0, j = 0;
+    bool active;
+    const Fq *a0, *a1;        // the factor that needs no negation
+    const Coef* bb;           // the factor whose -c1 is stored
+    if (op == P_SQR) {
+        active = t < 42;
+        // pair number -> (i, j), i <= j, rows of lengths 6, 5, 4, 3, 2, 1
+        uint32_t base = 0;
+        i = pr >= 6 ? 1 : 0; base = pr >= 6 ? 6 : 0;
+        if (pr >= 11) { i = 2; base = 11; }
+        if (pr >= 15) { i = 3; base = 15; }
+        if (pr >= 18) { i = 4; base = 18; }
+        if (pr >= 20) { i = 5; base = 20; }
+        j = i + (pr - base);
+        if (!active) { i = 0; j = 0; }
+        a0 = &reg[ra][i].c0; a1 = &reg[ra][i].c1; bb = &reg[ra][j];
+    } else if (op == P_MUL) {
+        active = t < 72;
+        i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;
+        a0 = &reg[ra][i].c0; a1 = &reg[ra][i].c1; bb = &reg[rb][j];
+    } else {
+        active = t < 72;
+        i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;     // x_i * l_j
+        a0 = &line[rb][j].c0; a1 = &line[rb][j].c1; bb = &reg[ra][i];
+    }
+    if (active) {
+        const Fq A0 = *a0, A1 = *a1;
+        const Fq B0 = coord ? bb->c1 : bb->c0, B1 = coord ? bb->c0 : bb->n1;
+        const Fq r = Fq::dot2_inl(A0, B0, A1, B1);
+        Fq* dst = coord ? &prod[i * 6 + j].c1 : &prod[i * 6 + j].c0;
+        *dst = r;
+        if (op == P_SQR && i != j) { Fq* d2 = coord ? &prod[j * 6 + i].c1 : &prod[j * 6 + i].c0; *d2 = r; }
+    }
+}
+// coefficient-wise operations, one lane per coefficient (t < 6)
+__device__ __forceinline__ void pair_coefficients(uint32_t op, uint32_t rd, uint32_t ra, Coef (*reg)[6], const PairingConsts* __restrict__ consts, uint32_t t) {
+    if (t >= 6) return;
+    const Coef x = reg[ra][t];
+    Coef r = x;
+    if (op == P_CONJ) {            // x^(p^6): w -> -w
+        if (t & 1u) { r.c0 = x.c0.neg(); r.c1 = x.n1; r.n1 = x.c1; }
+    } else if (op == P_FROB) {     // x^p: conjugate every coefficient, times gamma^k
+        if (t == 0) { r.c1 = x.n1; r.n1 = x.c1; }
+        else {
+            const Fq2 m = Fq2::mul(Fq2{x.c0, x.n1}, consts->gamma1[t]);
+            r.c0 = m.c0; r.c1 = m.c1; r.n1 = m.c1.neg();
+        }
+    } else if (op == P_INV2) {     // coefficient 0 <- its inverse in Fq2, the others <- 0
+        if (t == 0) {
+            const Fq nrm = x.c0.sqr() + x.c1.sqr();
+            const Fq ni = nrm.inv();
+            r.c0 = x.c0 * ni; r.c1 = x.n1 * ni; r.n1 = r.c1.neg();
+        } else { r.c0 = Fq::zero(); r.c1 = Fq::zero(); r.n1 = Fq::zero(); }
+    }
+    reg[rd][t] = r;                // P_COPY: r = x
+}
+__device__ __forceinline__ bool pair_is_one(const Coef* x) {
+    bool one = x[0].c0 == Fq::one() && x[0].c1.is_zero();
+    for (int k2 = 1; k2 < 6; ++k2) one = one && x[k2].c0.is_zero() && x[k2].c1.is_zero();
+    return one;
+}
+
 __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
                                                           const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
                                                           const uint32_t* __restrict__ prog, uint32_t n_ops, const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
@@ -225,78 +400,59 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
     for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
     __syncthreads();
     for (uint32_t pc = 0; pc < n_ops; ++pc) {
-        const uint32_t w = s.prog[pc];   // uniform
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.prog[pc]);   // uniform: decoded on the scalar unit
         const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
         if (op <= P_MULL) {
-            // ---- products: one dot2 per lane
-            const uint32_t pr = t >> 1, coord = t & 1u;
-            uint32_t i = 0, j = 0;
-            bool active;
-            const Fq *a0, *a1;        // the factor that needs no negation
-            const Coef* bb;           // the factor whose -c1 is stored
-            if (op == P_SQR) {
-                active = t < 42;
-                // pair number -> (i, j), i <= j, rows of lengths 6, 5, 4, 3, 2, 1
-                uint32_t base = 0;
-                i = pr >= 6 ? 1 : 0; base = pr >= 6 ? 6 : 0;
-                if (pr >= 11) { i = 2; base = 11; }
-                if (pr >= 15) { i = 3; base = 15; }
-                if (pr >= 18) { i = 4; base = 18; }
-                if (pr >= 20) { i = 5; base = 20; }
-                j = i + (pr - base);
-                if (!active) { i = 0; j = 0; }
-                a0 = &s.reg[ra][i].c0; a1 = &s.reg[ra][i].c1; bb = &s.reg[ra][j];
-            } else if (op == P_MUL) {
-                active = t < 72;
-                i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;
-                a0 = &s.reg[ra][i].c0; a1 = &s.reg[ra][i].c1; bb = &s.reg[rb][j];
-            } else {
-                active = t < 72;
-                i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;     // x_i * l_j
-                a0 = &s.line[rb][j].c0; a1 = &s.line[rb][j].c1; bb = &s.reg[ra][i];
-            }
-            if (active) {
-                const Fq A0 = *a0, A1 = *a1;
-                const Fq B0 = coord ? bb->c1 : bb->c0, B1 = coord ? bb->c0 : bb->n1;
-                const Fq r = Fq::dot2_inl(A0, B0, A1, B1);
-                Fq* dst = coord ? &s.prod[i * 6 + j].c1 : &s.prod[i * 6 + j].c0;
-                *dst = r;
-                if (op == P_SQR && i != j) { Fq* d2 = coord ? &s.prod[j * 6 + i].c1 : &s.prod[j * 6 + i].c0; *d2 = r; }
-            }
+            pair_products(op, ra, rb, s.line, s.reg, s.prod, t);
             __syncthreads();
             // ---- fold
             if (t < 72) fq12_fold(s.prod, s.reg[rd], t);
             __syncthreads();
         } else if (op == P_CHECK) {
-            if (t == 0) {
-                bool one = s.reg[ra][0].c0 == Fq::one() && s.reg[ra][0].c1.is_zero();
-                for (int k2 = 1; k2 < 6; ++k2) one = one && s.reg[ra][k2].c0.is_zero() && s.reg[ra][k2].c1.is_zero();
-                ok[chk] = one ? 1u : 0u;
-            }
+            if (t == 0) ok[chk] = pair_is_one(s.reg[ra]) ? 1u : 0u;
         } else {
-            // ---- coefficient-wise operations, one lane per coefficient
-            if (t < 6) {
-                const Coef x = s.reg[ra][t];
-                Coef r = x;
-                if (op == P_CONJ) {            // x^(p^6): w -> -w
-                    if (t & 1u) { r.c0 = x.c0.neg(); r.c1 = x.n1; r.n1 = x.c1; }
-                } else if (op == P_FROB) {     // x^p: conjugate every coefficient, times gamma^k
-                    if (t == 0) { r.c1 = x.n1; r.n1 = x.c1; }
-                    else {
-                        const Fq2 m = Fq2::mul(Fq2{x.c0, x.n1}, consts->gamma1[t]);
-                        r.c0 = m.c0; r.c1 = m.c1; r.n1 = m.c1.neg();
-                    }
-                } else if (op == P_INV2) {     // coefficient 0 <- its inverse in Fq2, the others <- 0
-                    if (t == 0) {
-                        const Fq nrm = x.c0.sqr() + x.c1.sqr();
-                        const Fq ni = nrm.inv();
-                        r.c0 = x.c0 * ni; r.c1 = x.n1 * ni; r.n1 = r.c1.neg();
-                    } else { r.c0 = Fq::zero(); r.c1 = Fq::zero(); r.n1 = Fq::zero(); }
-                }
-                s.reg[rd][t] = r;              // P_COPY: r = x
-            }
+            pair_coefficients(op, rd, ra, s.reg, consts, t);
             __syncthreads();
         }
+    }
+}
+
+// Two operation streams per check (pairing_program2): 256 threads, group g = t / 128 executes column g of every step.  The line
+// products always come from k_pair_lines.
+struct alignas(16) PairShared2 {
+    Fq2 line[PAIR_ITERS][6];
+    Fq2 prod[2][36];
+    Coef reg[PAIR2_REGS][6];
+    uint2 prog[PAIR2_MAX_STEPS];
+};
+__global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, const PairingConsts* __restrict__ consts, const uint2* __restrict__ prog, uint32_t n_steps,
+                                                               const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ PairShared2 s;
+    const uint32_t chk = blockIdx.x, t = threadIdx.x, g = t / PAIR_THREADS, tl = t % PAIR_THREADS;
+    if (chk >= n) return;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(pre + (size_t)chk * PAIR_ITERS * 6);
+        uint4* dst = reinterpret_cast<uint4*>(&s.line[0][0]);
+        for (uint32_t k = t; k < PAIR_ITERS * 6 * sizeof(Fq2) / 16; k += 2 * PAIR_THREADS) dst[k] = src[k];
+    }
+    if (t < 12) {   // registers 0 and 1 (the two halves of the Miller value) start at one
+        Coef c; c.c0 = (t % 6) == 0 ? Fq::one() : Fq::zero(); c.c1 = Fq::zero(); c.n1 = Fq::zero();
+        s.reg[t / 6][t % 6] = c;
+    }
+    for (uint32_t k = t; k < n_steps; k += 2 * PAIR_THREADS) s.prog[k] = prog[k];
+    __syncthreads();
+    for (uint32_t pc = 0; pc < n_steps; ++pc) {
+        const uint2 w2 = s.prog[pc];
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g ? w2.y : w2.x));   // uniform per wave: decoded on the scalar unit
+        const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
+        const bool product = op >= P_SQR && op <= P_MULL;
+        if (product) pair_products(op, ra, rb, s.line, s.reg, s.prod[g], tl);
+        else if (op == P_CHECK) { if (tl == 0) ok[chk] = pair_is_one(s.reg[ra]) ? 1u : 0u; }
+        else if (op) pair_coefficients(op, rd, ra, s.reg, consts, tl);
+        __syncthreads();
+        if (product && tl < 72) fq12_fold(s.prod[g], s.reg[rd], tl);
+        __syncthreads();
     }
 }
 
@@ -424,7 +580,9 @@ int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot*
     }
     for (int i = 64; i < PAIR_ITERS; ++i) { its.first[i] = (uint8_t)line++; its.cnt[i] = 1; }
     hipLaunchKernelGGL(k_pair_lines, dim3(PAIR_ITERS, n), dim3(PL_THREADS), 0, s, d_ready, parts, tab, its, lines);
-    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog_merged, pd.n_ops_merged, (const Fq2*)lines, d_ok);
+    static const bool one_stream = getenv("H2V_PAIRING_ONE_STREAM") != nullptr;   // knob: the single-stream table over the same lines
+    if (pd.prog2 && !one_stream) hipLaunchKernelGGL(k_pairing2, dim3(n), dim3(2 * PAIR_THREADS), 0, s, n, pd.consts, reinterpret_cast<const uint2*>(pd.prog2), pd.n_steps2, (const Fq2*)lines, d_ok);
+    else hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog_merged, pd.n_ops_merged, (const Fq2*)lines, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

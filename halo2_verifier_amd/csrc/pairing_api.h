@@ -16,6 +16,7 @@ bool params_from_bytes(const uint8_t* data, size_t len, int format, ParamsHost& 
 
 PairingConsts pairing_consts_host();
 std::vector<uint32_t> pairing_program(bool merged_lines);
+std::vector<uint32_t> pairing_program2();   // two operation streams per check: [step][2]
 
 #define H2V_PAIRING_LINES 102   // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
 #define H2V_PAIRING_LINE_WS_BYTES ((size_t)66 * 6 * sizeof(Fq2))   // per check: k_pair_lines' output, one Fq12 per Miller iteration (+ 2 corrections)
@@ -35,6 +36,8 @@ struct PairingDevice {
     uint32_t n_ops = 0;
     uint32_t* prog_merged = nullptr;   // the same with one line product per Miller iteration (checks over split accumulators)
     uint32_t n_ops_merged = 0;
+    uint32_t* prog2 = nullptr;         // two streams per check (k_pairing2): uint2 per step
+    uint32_t n_steps2 = 0;
     int upload(const ParamsHost& p);
     void release();
 };

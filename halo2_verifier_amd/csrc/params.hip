@@ -134,6 +134,11 @@ int PairingDevice::upload(const ParamsHost& p) {
     H2V_HIP_CHECK(hipMemcpy(prog, ops.data(), 4 * ops.size(), hipMemcpyHostToDevice));
     H2V_HIP_CHECK(hipMalloc(&prog_merged, 4 * opsm.size()));
     H2V_HIP_CHECK(hipMemcpy(prog_merged, opsm.data(), 4 * opsm.size(), hipMemcpyHostToDevice));
+    const std::vector<uint32_t> ops2 = pairing_program2();
+    n_steps2 = (uint32_t)(ops2.size() / 2);
+    if (n_steps2 > 448) { set_last_error("pairing: two-stream table too long"); return H2V_ERR_DEVICE; }
+    H2V_HIP_CHECK(hipMalloc(&prog2, 4 * ops2.size()));
+    H2V_HIP_CHECK(hipMemcpy(prog2, ops2.data(), 4 * ops2.size(), hipMemcpyHostToDevice));
     return 0;
 }
 // 2^shift * q by the Miller loop's own doubling step (homogeneous projective), back to affine
@@ -174,6 +179,8 @@ void PairingDevice::release() {
     if (consts) hipFree(consts);
     if (prog) hipFree(prog);
     if (prog_merged) hipFree(prog_merged);
+    if (prog2) hipFree(prog2);
+    prog2 = nullptr; n_steps2 = 0;
     prog_merged = nullptr; n_ops_merged = 0;
     l_sg2 = l_ng2 = nullptr; consts = nullptr; prog = nullptr; n_ops = 0;
 }
