@@ -451,20 +451,18 @@ struct SlotFile {
     }
 };
 
-__global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
-    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
-    extern __shared__ uint32_t frvm_lds[];
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n) return;
+// one instruction stream over the slot file `sf` of proof p; `live` = p is a real proof (lanes past the end of a two-stream
+// workgroup keep running for the barriers but touch no memory of their own)
+template <bool TWO> __device__ __forceinline__ void frvm_run(const FrvmArgs& a, const VmInstr* __restrict__ code, uint32_t n_code, const SlotFile& sf, uint32_t p, bool live) {
     const uint32_t n = a.n;
-    const SlotFile sf{frvm_lds, lds_slots, a.slots, n, p, threadIdx.x};
     // an operand of MUL / ADD / SUB is a slot or (VM_CONST_OPERAND) a program constant, read with uniform loads
     auto opnd = [&](uint32_t x) -> Fr { return (x & VM_CONST_OPERAND) ? a.consts[x & ~VM_CONST_OPERAND] : sf.load(x); };
-    VmInstr nx = a.code[0];
-    for (uint32_t pc = 0; pc < a.n_code; ++pc) {
+    VmInstr nx = code[0];
+    for (uint32_t pc = 0; pc < n_code; ++pc) {
         const VmInstr in = nx;  // wave-uniform; the next instruction is fetched while this one executes
-        nx = a.code[pc + 1 < a.n_code ? pc + 1 : pc];
+        nx = code[pc + 1 < n_code ? pc + 1 : pc];
         switch (in.op) {
+            case OP_BARRIER: if (TWO) __syncthreads(); break;
             case OP_CONST: sf.store(in.d, a.consts[in.a]); break;
             case OP_MUL: sf.store(in.d, Fr::mul_inl(opnd(in.a), opnd(in.b))); break;
             case OP_ADD: sf.store(in.d, opnd(in.a) + opnd(in.b)); break;
@@ -472,7 +470,7 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
             case OP_NEG: sf.store(in.d, sf.load(in.a).neg()); break;
             case OP_INV: {
                 Fr v = sf.load(in.a);
-                if (v.is_zero()) status_set(a.status, p, H2V_DEV_ST_PANIC);
+                if (live && v.is_zero()) status_set(a.status, p, H2V_DEV_ST_PANIC);
                 // all lanes invert at once: the divsteps of Fp::inv are branch-free, so the wave stays uniform
                 sf.store(in.d, v.inv());
                 break;
@@ -494,20 +492,20 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
                 sf.load(in.a).to_raw(raw);
                 bool bad = a.status[p] != 0;
                 uint32_t* dst = a.msm_scal + ((size_t)p * a.np + in.b) * 8;
-                for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
+                if (live) for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
             }
             case OP_STORE_GUARD: {
                 uint32_t raw[8];
                 sf.load(in.a).to_raw(raw);
                 uint32_t* dst = a.guard_scal + ((size_t)p * a.n_guard + in.b) * 8;
-                for (int i = 0; i < 8; ++i) dst[i] = raw[i];
+                if (live) for (int i = 0; i < 8; ++i) dst[i] = raw[i];
                 break;
             }
             case OP_STORE_SHARED: {
                 Fr v = sf.load(in.a);
                 if (a.status[p] != 0) v = Fr::zero();
-                a.shared[(size_t)in.b * n + p] = v;
+                if (live) a.shared[(size_t)in.b * n + p] = v;
                 break;
             }
             case OP_STORE_LEFT: {
@@ -515,12 +513,34 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
                 sf.load(in.a).to_raw(raw);
                 bool bad = a.status[p] != 0;
                 uint32_t* dst = a.left_scal + ((size_t)p * a.np + in.b) * 8;
-                for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
+                if (live) for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
             }
             default: break;
         }
     }
+}
+__global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
+    extern __shared__ uint32_t frvm_lds[];
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const SlotFile sf{frvm_lds, lds_slots, a.slots, a.n, p, threadIdx.x};
+    frvm_run<false>(a, a.code, a.n_code, sf, p, true);
+}
+// Two instruction streams per proof (vkplan.hip: Builder::emit2): the two waves of a workgroup work on the SAME 64 proofs — wave w
+// runs stream w — and share the slot file; values cross between them over OP_BARRIER only.  While one wave sits in the batched
+// inversion's single inverse (a sixth of the program's work, indivisible), the other evaluates the expressions that do not need it.
+__global__ void __launch_bounds__(128) k_frvm2(FrvmArgs a, uint32_t lds_slots) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ uint32_t frvm_lds[];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t p_raw = blockIdx.x * 64 + lane;
+    const bool live = p_raw < a.n;
+    const uint32_t p = live ? p_raw : a.n - 1;   // lanes past the end shadow the last proof: they read its inputs, write nothing, and keep the barriers whole
+    // (a shadow lane has its own LDS lane but shares the last proof's global slots: it writes there exactly what that proof's lane writes)
+    const SlotFile sf{frvm_lds, lds_slots, a.slots, a.n, p, lane};
+    frvm_run<true>(a, w ? a.code2[1] : a.code2[0], w ? a.n_code2[1] : a.n_code2[0], sf, p, live);
 }
 
 // msm_scal[n*np + g*n_shared + j] = canonical( sum over the proofs p of group g of shared[j][p] )
@@ -601,11 +621,14 @@ int instance_eval_enqueue(hipStream_t s, const InstEvalArgs& a) {
 }
 int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     if (!a.n) return 0;
-    // LDS for the hottest slots: 2304 bytes per slot and wave.  Every wave should still get a CU of its own (a program is a
-    // latency chain, and a second wave on the CU slows both), so the budget follows the number of waves: the whole 160 KB of a
-    // CU while there are at most 256 waves, half of it up to 384.
+    // LDS for the hottest slots: 2304 bytes per slot and 64 proofs.  Every wave should still get a SIMD of its own (a program is a
+    // latency chain), so the budget follows the number of workgroups: the whole 160 KB of a CU while there are at most 256,
+    // half of it up to 384.
     const uint32_t waves = (a.n + 63) / 64;
-    // (a launch with more waves than that is a throughput launch — several of them are in flight — and an LDS-hungry kernel keeps
+    static const bool one_stream = getenv("H2V_FRVM_ONE_STREAM") != nullptr;
+    const bool two = a.code2[0] && a.code2[1] && a.n_code2[0] && a.n_code2[1] && !one_stream;
+    if (two) n_slots = a.n_slots2;
+    // (a launch with more workgroups than that is a throughput launch — several of them are in flight — and an LDS-hungry kernel keeps
     // the other kernels' workgroups off its CUs: a small slice then)
     uint32_t budget = waves <= 256 ? 156 * 1024 : (waves <= 384 ? 78 * 1024 : 36 * 1024);
     if (const char* e = getenv("H2V_FRVM_LDS_KB")) budget = (uint32_t)atoi(e) * 1024;   // tuning knob
@@ -614,9 +637,11 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     static std::atomic<size_t> granted{0};   // raising the limit is per function and sticky; do it once per size class
     if (lds > 64 * 1024 && granted.load() < lds) {
         H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_frvm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_frvm2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         granted.store(160 * 1024);
     }
-    hipLaunchKernelGGL(k_frvm, dim3(waves), dim3(64), lds, s, a, lds_slots);
+    if (two) hipLaunchKernelGGL(k_frvm2, dim3(waves), dim3(128), lds, s, a, lds_slots);
+    else hipLaunchKernelGGL(k_frvm, dim3(waves), dim3(64), lds, s, a, lds_slots);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -61,6 +61,7 @@ enum VmOp : uint32_t {
     OP_STORE_LEFT = 15,   // left_scalars[proof][point slot b] <- canonical(a)
     OP_LOAD_INSTEVAL = 16, // d <- instance-query evaluation #a of this proof, computed by k_instance_eval (wide instance vectors)
     OP_STORE_GUARD = 17,   // guard_scalars[proof][term b] <- canonical(a): one scalar per term of the Guard in reference order (h2v_guard_msm, GWC)
+    OP_BARRIER = 18,       // two-stream programs: both streams of a proof meet here (values cross between them only over a barrier)
 };
 struct VmInstr { uint32_t op, d, a, b; };
 #define VM_CONST_OPERAND 0x80000000u   // operand a / b of MUL, ADD, SUB: consts[index] instead of a slot
@@ -90,6 +91,8 @@ struct Plan {
     std::vector<VmInstr> code;
     std::vector<Fr> consts;
     uint32_t n_slots = 0;
+    std::vector<VmInstr> code2[2];          // the same program as two instruction streams per proof (k_frvm2), with its own slot numbering
+    uint32_t n_slots2 = 0;
     // MSM map
     uint32_t n_shared = 0;                  // fixed (queried) + permutation + g
     std::vector<G1A> shared_bases;
@@ -116,6 +119,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
 struct PlanDevice {
     Plan host;
     VmInstr* code = nullptr;
+    VmInstr* code2[2] = {nullptr, nullptr};
     Fr* consts = nullptr;
     TranscriptSrc* stream = nullptr;
     uint32_t* squeeze_at = nullptr;

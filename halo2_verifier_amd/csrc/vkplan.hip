@@ -287,6 +287,213 @@ struct Builder {
         }
         n_slots = next ? next : 1;
     }
+
+    // ---- The same program as TWO instruction streams per proof (k_frvm2: two waves of a workgroup work on the same 64 proofs and
+    // share their slot file).  A proof's program is a latency chain with one long indivisible block in the middle — the batched
+    // inversion's single inverse, ~60 products' worth — and most of the expression evaluation does not depend on it.  List
+    // scheduling on two processors: the stream that is behind takes the ready node it can start soonest (ties: longest path to the
+    // end first); a value crosses between the streams only over an OP_BARRIER, which both streams execute (it aligns their clocks, so
+    // the scheduler places one only when the consumer cannot start earlier anyway).  Loads and materialised constants are private:
+    // a stream (re)loads what it needs right before the first use.
+    // Slots: a value touched by one stream only is recycled in that stream's program order; a shared one becomes free at the first
+    // barrier after its last use, for either stream.
+    static double op_weight(const Node& nd) {
+        switch (nd.op) {
+            case OP_MUL: return 1.0;
+            case OP_ADD: case OP_SUB: case OP_NEG: return 0.15;
+            case OP_INV: return 60.0;
+            case OP_POW: { double w = 0; for (uint32_t e = nd.imm; e > 1; e >>= 1) w += 1.5; return w; }
+            case OP_SQRN: return (double)nd.imm;
+            case OP_CONST: return 0.1;
+            default: return 0.5;   // loads (from_raw) and stores (to_raw)
+        }
+    }
+    mutable double makespan2 = 0;   // the scheduler's estimate for emit2's program, in products
+    void emit2(std::vector<VmInstr> code[2], uint32_t& n_slots) const {
+        const size_t n = nodes.size();
+        static const double BAR = getenv("H2V_FRVM_BAR") ? atof(getenv("H2V_FRVM_BAR")) : 0.3;   // what the scheduler charges for a barrier, in products
+        auto n_operands = [&](const Node& nd) -> int {
+            switch (nd.op) {
+                case OP_MUL: case OP_ADD: case OP_SUB: return 2;
+                case OP_NEG: case OP_INV: case OP_POW: case OP_SQRN: case OP_STORE_MSM: case OP_STORE_SHARED: case OP_STORE_LEFT: case OP_STORE_GUARD: return 1;
+                default: return 0;
+            }
+        };
+        auto is_compute = [&](Val v) { return nodes[v].op != OP_CONST && !is_load(nodes[v].op); };
+        auto inline_const = [&](const Node& consumer, Val v) { return nodes[v].op == OP_CONST && takes_const_operands(consumer.op); };
+        // longest path to the end (compute nodes)
+        std::vector<double> bl(n, 0.0);
+        std::vector<std::vector<Val>> succ(n);
+        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) for (int j = 0; j < n_operands(nodes[i]); ++j) { const Val v = j ? nodes[i].b : nodes[i].a; if (is_compute(v) && !(j == 1 && nodes[i].b == nodes[i].a)) succ[v].push_back((Val)i); }
+        for (size_t i = n; i-- > 0;) if (is_compute((Val)i)) { double m = 0; for (Val sc : succ[i]) m = std::max(m, bl[sc]); bl[i] = m + op_weight(nodes[i]); }
+        struct Item { int kind; Val v; double fin; };   // 0: compute node, 1: private load / constant, 2: barrier; fin: scheduled finish time
+        std::vector<Item> items[2];
+        std::vector<int> stream_of(n, -1);
+        std::vector<uint32_t> bar_at(n, 0);      // barriers of its stream that precede the node
+        std::vector<size_t> pos(n, 0);           // index of the node's item in its stream
+        std::vector<char> loaded[2] = {std::vector<char>(n, 0), std::vector<char>(n, 0)};
+        std::vector<int> missing(n, 0);
+        std::vector<Val> ready;
+        size_t left = 0;
+        auto is_store = [&](Val v) { const uint32_t op = nodes[v].op; return op == OP_STORE_MSM || op == OP_STORE_SHARED || op == OP_STORE_LEFT || op == OP_STORE_GUARD; };
+        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) {
+            ++left;
+            int m = 0;
+            for (int j = 0; j < n_operands(nodes[i]); ++j) { const Val v = j ? nodes[i].b : nodes[i].a; if (is_compute(v) && !(j == 1 && nodes[i].b == nodes[i].a)) ++m; }
+            missing[i] = m;
+            if (!m) ready.push_back((Val)i);
+        }
+        double clk[2] = {0, 0};
+        uint32_t bars = 0;
+        Val last_node = (Val)-1;
+        static const double SLACK = getenv("H2V_FRVM_SLACK") ? atof(getenv("H2V_FRVM_SLACK")) : 1.0;
+        // where stream q could start v: its own clock, or — if an operand sits in the other stream o behind no barrier yet — after a
+        // new barrier, placed in o right behind the last such operand or, if q is ahead of that, behind the first later item of o that
+        // ends after q's clock (so that o does not wait for q), and at the end of q
+        struct Place { bool bar; size_t p; double start; };
+        auto place = [&](Val v, int q) -> Place {
+            const int o = q ^ 1;
+            bool need = false; size_t pmax = 0;
+            for (int j = 0; j < n_operands(nodes[v]); ++j) {
+                const Val u = j ? nodes[v].b : nodes[v].a;
+                if (is_compute(u) && stream_of[u] == o && bar_at[u] == bars) { pmax = need ? std::max(pmax, pos[u]) : pos[u]; need = true; }
+            }
+            if (!need) return Place{false, 0, clk[q]};
+            size_t p = pmax;
+            while (p + 1 < items[o].size() && items[o][p].fin < clk[q]) ++p;
+            return Place{true, p, std::max(items[o][p].fin, clk[q]) + BAR};
+        };
+        auto append = [&](int q, Val v) {
+            for (int j = 0; j < n_operands(nodes[v]); ++j) {
+                const Val u = j ? nodes[v].b : nodes[v].a;
+                if (is_compute(u) || inline_const(nodes[v], u) || loaded[q][u]) continue;
+                clk[q] += op_weight(nodes[u]); items[q].push_back({1, u, clk[q]}); loaded[q][u] = 1;
+            }
+            clk[q] += op_weight(nodes[v]);
+            pos[v] = items[q].size(); items[q].push_back({0, v, clk[q]});
+            stream_of[v] = q; bar_at[v] = bars; --left;
+        };
+        while (left) {
+            // the ready node with the longest tail; the stream where it finishes first
+            size_t best = 0;
+            for (size_t r = 1; r < ready.size(); ++r) if (bl[ready[r]] > bl[ready[best]] + 1e-9) best = r;
+            // (within a small slack of the longest tail, a consumer of the node scheduled last goes first: values are used while they are
+            // fresh, which keeps the number of live slots near the single-stream program's)
+            if (last_node != (Val)-1) {
+                const double top = bl[ready[best]];
+                size_t loc = (size_t)-1;
+                for (size_t r = 0; r < ready.size(); ++r) {
+                    if (bl[ready[r]] < top - SLACK) continue;
+                    const Node& nd = nodes[ready[r]];
+                    bool uses = false;
+                    for (int j = 0; j < n_operands(nd); ++j) if ((j ? nd.b : nd.a) == last_node) uses = true;
+                    if (uses && (loc == (size_t)-1 || bl[ready[r]] > bl[ready[loc]])) loc = r;
+                }
+                if (loc != (size_t)-1) best = loc;
+            }
+            const Val v = ready[best];
+            last_node = v;
+            ready.erase(ready.begin() + (ptrdiff_t)best);
+            const Place pl[2] = {place(v, 0), place(v, 1)};
+            int q = pl[0].start < pl[1].start - 1e-9 ? 0 : (pl[1].start < pl[0].start - 1e-9 ? 1 : (pl[0].bar ? 1 : 0));
+            if (pl[q].bar) {
+                const int o = q ^ 1;
+                const double tb = pl[q].start;                       // both streams leave the barrier at tb
+                const size_t p = pl[q].p;
+                const double shift = tb - items[o][p].fin;            // what the items of o behind the barrier are delayed by
+                items[o].insert(items[o].begin() + (ptrdiff_t)p + 1, Item{2, 0, tb});
+                for (size_t k = p + 2; k < items[o].size(); ++k) {
+                    items[o][k].fin += shift;
+                    if (items[o][k].kind == 0) { pos[items[o][k].v] = k; bar_at[items[o][k].v] = bars + 1; }
+                }
+                clk[o] = items[o].back().fin;
+                items[q].push_back(Item{2, 0, tb});
+                clk[q] = tb;
+                ++bars;
+            }
+            append(q, v);
+            // its stores at once, on the same stream: they free the slot and need no barrier
+            std::vector<Val> now_ready;
+            for (Val sc : succ[v]) if (--missing[sc] == 0) now_ready.push_back(sc);
+            for (Val sc : now_ready) { if (is_store(sc)) append(q, sc); else ready.push_back(sc); }
+        }
+        makespan2 = std::max(clk[0], clk[1]);
+        // ---- slots.  Value ids: compute node v -> v; private load / constant u of stream q -> n * (1 + q) + u
+        auto value_of = [&](Val u, int q) -> size_t { return is_compute(u) ? (size_t)u : n * (size_t)(1 + q) + u; };
+        const size_t NV = 3 * n;
+        std::vector<uint32_t> last_epoch(NV, 0), slot(NV, 0);
+        std::vector<char> shared(NV, 0), has_def(NV, 0);
+        std::vector<int> owner(NV, -1);
+        std::vector<size_t> last_pos(NV, 0);   // position of the last use in the owner's stream (private values)
+        for (int q = 0; q < 2; ++q) {
+            uint32_t ep = 0;
+            for (size_t k = 0; k < items[q].size(); ++k) {
+                const Item& it = items[q][k];
+                if (it.kind == 2) { ++ep; continue; }
+                const Node& nd = nodes[it.v];
+                auto touch = [&](size_t id) {
+                    if (owner[id] == -1) owner[id] = q; else if (owner[id] != q) shared[id] = 1;
+                    last_epoch[id] = std::max(last_epoch[id], ep);
+                    if (owner[id] == q) last_pos[id] = k;
+                };
+                if (it.kind == 0) for (int j = 0; j < n_operands(nd); ++j) { const Val u = j ? nd.b : nd.a; if (!inline_const(nd, u)) touch(value_of(u, q)); }
+                if (nd.has_result) { const size_t id = it.kind == 1 ? value_of(it.v, q) : (size_t)it.v; has_def[id] = 1; touch(id); }
+            }
+        }
+        // a value's owner is the stream of its definition for compute nodes: fix the cases where a use was seen first (other stream, later epoch)
+        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i) && stream_of[i] >= 0 && owner[i] != stream_of[i]) { owner[i] = stream_of[i]; shared[i] = 1; }
+        uint32_t next = 0;
+        std::vector<uint32_t> local_free[2];
+        std::vector<std::pair<uint32_t, uint32_t>> pool;   // (slot, first epoch it may be reused in)
+        std::vector<std::vector<size_t>> release_after(1);  // shared values by last epoch
+        for (size_t id = 0; id < NV; ++id) if (has_def[id] && shared[id]) { if (release_after.size() <= last_epoch[id]) release_after.resize(last_epoch[id] + 1); release_after[last_epoch[id]].push_back(id); }
+        size_t cur[2] = {0, 0};
+        uint32_t ep = 0;
+        auto take = [&](int q) -> uint32_t {
+            if (!local_free[q].empty()) { auto itf = std::min_element(local_free[q].begin(), local_free[q].end()); const uint32_t sl = *itf; local_free[q].erase(itf); return sl; }
+            size_t bi = (size_t)-1;
+            for (size_t k = 0; k < pool.size(); ++k) if (pool[k].second <= ep && (bi == (size_t)-1 || pool[k].first < pool[bi].first)) bi = k;
+            if (bi != (size_t)-1) { const uint32_t sl = pool[bi].first; pool.erase(pool.begin() + (ptrdiff_t)bi); return sl; }
+            return next++;
+        };
+        for (;;) {
+            for (int q = 0; q < 2; ++q) {
+                size_t& k = cur[q];
+                for (; k < items[q].size() && items[q][k].kind != 2; ++k) {
+                    const Item& it = items[q][k];
+                    const Node& nd = nodes[it.v];
+                    VmInstr in{nd.op, 0, 0, 0};
+                    auto opnd = [&](Val u) -> uint32_t { return inline_const(nd, u) ? (VM_CONST_OPERAND | nodes[u].imm) : slot[value_of(u, q)]; };
+                    if (it.kind == 1) in.a = nd.imm;
+                    else switch (nd.op) {
+                        case OP_MUL: case OP_ADD: case OP_SUB: in.a = opnd(nd.a); in.b = opnd(nd.b); break;
+                        case OP_NEG: case OP_INV: in.a = opnd(nd.a); break;
+                        default: in.a = opnd(nd.a); in.b = nd.imm; break;   // POW / SQRN / STORE_*
+                    }
+                    // private operands that die here free their slots first: the interpreter reads before it writes
+                    if (it.kind == 0) for (int j = 0; j < n_operands(nd); ++j) {
+                        const Val u = j ? nd.b : nd.a;
+                        if (inline_const(nd, u) || (j == 1 && nd.b == nd.a)) continue;
+                        const size_t id = value_of(u, q);
+                        if (!shared[id] && last_pos[id] == k) local_free[q].push_back(slot[id]);
+                    }
+                    if (nd.has_result) {
+                        const size_t id = it.kind == 1 ? value_of(it.v, q) : (size_t)it.v;
+                        slot[id] = take(q); in.d = slot[id];
+                        if (!shared[id] && last_pos[id] == k) local_free[q].push_back(slot[id]);   // never used
+                    }
+                    code[q].push_back(in);
+                }
+            }
+            if (cur[0] >= items[0].size() && cur[1] >= items[1].size()) break;
+            // both streams stand at the same barrier
+            code[0].push_back(VmInstr{OP_BARRIER, 0, 0, 0}); code[1].push_back(VmInstr{OP_BARRIER, 0, 0, 0});
+            ++cur[0]; ++cur[1];
+            if (ep < release_after.size()) for (size_t id : release_after[ep]) pool.push_back({slot[id], ep + 1});
+            ++ep;
+        }
+        n_slots = next ? next : 1;
+    }
 };
 
 enum CommitKind { K_ADVICE, K_PERM_PRODUCT, K_LOOKUP, K_SHUFFLE, K_FIXED, K_PERM_COMMON, K_H_MSM, K_RANDOM };
@@ -827,6 +1034,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     for (uint32_t s2 = 0; s2 < np; ++s2) if (left_scalar[s2] != (Val)-1) b.store_left(b.mul(left_scalar[s2], mult), s2);
 
     b.emit(plan.code, plan.n_slots);
+    b.emit2(plan.code2, plan.n_slots2);
     if (getenv("H2V_DUMP_PLAN")) {   // diagnostic: size and instruction mix of the compiled Fr program
         std::map<uint32_t, size_t> hist;
         for (const VmInstr& in : plan.code) ++hist[in.op];
@@ -834,6 +1042,36 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
                 b.consts.size(), plan.stream.size(), plan.n_points, plan.n_shared);
         for (auto& kv : hist) fprintf(stderr, " %u:%zu", kv.first, kv.second);
         fprintf(stderr, "\n");
+        // the DAG's work and critical path in units of one Fr product (how much a second instruction stream per proof could gain)
+        auto weight = [](const Node& nd) -> double {
+            switch (nd.op) {
+                case OP_MUL: return 1.0;
+                case OP_ADD: case OP_SUB: case OP_NEG: return 0.15;
+                case OP_INV: return 60.0;
+                case OP_POW: { double w = 0; for (uint32_t e = nd.imm; e > 1; e >>= 1) w += 1.5; return w; }
+                case OP_SQRN: return (double)nd.imm;
+                case OP_CONST: return 0.0;
+                default: return 0.5;   // loads (from_raw) and stores (to_raw)
+            }
+        };
+        std::vector<double> depth(b.nodes.size(), 0.0);
+        double work = 0, cp = 0;
+        for (size_t i = 0; i < b.nodes.size(); ++i) {
+            const Node& nd = b.nodes[i];
+            double d0 = 0;
+            const bool two = nd.op == OP_MUL || nd.op == OP_ADD || nd.op == OP_SUB;
+            const bool one = two || nd.op == OP_NEG || nd.op == OP_INV || nd.op == OP_POW || nd.op == OP_SQRN || nd.op == OP_STORE_MSM || nd.op == OP_STORE_SHARED || nd.op == OP_STORE_LEFT || nd.op == OP_STORE_GUARD;
+            if (one) d0 = depth[nd.a];
+            if (two) d0 = std::max(d0, depth[nd.b]);
+            depth[i] = d0 + weight(nd);
+            work += weight(nd); cp = std::max(cp, depth[i]);
+        }
+        fprintf(stderr, "[h2v plan] DAG work %.1f products, critical path %.1f (%zu nodes)\n", work, cp, b.nodes.size());
+        for (int q = 0; q < 2; ++q) {
+            double w = 0; size_t bars = 0;
+            for (const VmInstr& in : plan.code2[q]) { if (in.op == OP_BARRIER) { ++bars; continue; } Node nd{in.op, 0, 0, in.b, false}; w += Builder::op_weight(nd); }
+            fprintf(stderr, "[h2v plan] stream %d: %zu instructions, %zu barriers, %.1f products of work; %u slots; estimated makespan %.1f\n", q, plan.code2[q].size(), bars, w, plan.n_slots2, b.makespan2);
+        }
     }
     plan.consts = b.consts;
     // LOAD_CHAL immediates already refer to squeeze order
@@ -850,6 +1088,7 @@ template <class T> static int upload_vec(const std::vector<T>& v, T*& d) {
 int PlanDevice::upload() {
     int rc;
     if ((rc = upload_vec(host.code, code))) return rc;
+    for (int q = 0; q < 2; ++q) if ((rc = upload_vec(host.code2[q], code2[q]))) return rc;
     if ((rc = upload_vec(host.consts, consts))) return rc;
     if ((rc = upload_vec(host.stream, stream))) return rc;
     if ((rc = upload_vec(host.squeeze_at, squeeze_at))) return rc;
@@ -859,7 +1098,7 @@ int PlanDevice::upload() {
     return 0;
 }
 void PlanDevice::release() {
-    hipFree(code); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases);
+    hipFree(code); hipFree(code2[0]); hipFree(code2[1]); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases);
     code = nullptr; consts = nullptr; stream = nullptr; squeeze_at = nullptr; point_offsets = nullptr; scalar_offsets = nullptr; shared_bases = nullptr;
 }
 
