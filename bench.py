@@ -262,7 +262,7 @@ def rank_main(args):
         for s, g in zip(streams, sizes):
             b = h2v.Batch(ctx, B * g, N_PUBLIC, stream=s.cuda_stream, groups=g)
             b.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
-            b.set_profiling(True)
+            b.set_profiling(h2v.Batch.PROFILE_KERNEL)   # timed region: only the dominant kernel's own timestamps (stage events are barrier packets)
             batches.append(b)
         acc_local = [torch.empty(h2d.ACC_BYTES * g, dtype=torch.uint8, device=dev) for g in sizes]
         gathered = [None] * len(sizes)
@@ -327,6 +327,7 @@ def rank_main(args):
         # roofline figure uses these undisturbed durations; they agree with the rocprofv3 depth-1 summary under profiles/.
         isolated = None
         if isolated_launches:
+            batches[0].set_profiling(True)
             for k2 in stage_sum:
                 stage_sum[k2] = 0.0
             stage_cnt[0] = 0
@@ -343,7 +344,7 @@ def rank_main(args):
         terms_launch = G * (n_local * shape["n_points"] + n_shared + n_local)
         return dict(dt=dt, G=G, launches=launches, rem=rem, depth=depth, total=total, stages=stages, isolated=isolated, terms_launch=terms_launch, B=B)
 
-    m = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=args.reupload, isolated_launches=4 if world == 1 else 0)
+    m = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=args.reupload, isolated_launches=4 if world == 1 else 2)
     m_re = None
     if world == 1 and not args.reupload and not args.no_reupload_leg:
         # PCIe-inclusive leg (SURVEY.md §8d timing method): the same K steps with the host buffers copied to the device again
@@ -369,7 +370,8 @@ def rank_main(args):
             valu = (tj or {}).get("valu_active", {}).get("h2v::msm_accumulate")
         except Exception:
             pass
-        kernels = {"msm_accumulate": {"ms": acc_ms, "alg_GBps": (96.0 * terms_total) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None,
+        kernels = {"msm_accumulate": {"ms": acc_ms, "ms_timed_region": stages.get("msm_accumulate", 0.0),
+                                      "timing": "the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL events), every launch of the timed region", "alg_GBps": (96.0 * terms_total) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None,
                                       "valu_active": valu, "valu_active_source": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the committed --pmc pass named in traffic_source"}}
         workload = (f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
                     f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step" + (f" for all {world} x {B} proofs" if world > 1 else "") + f"), {args.distinct} distinct proofs; "
@@ -395,14 +397,14 @@ def rank_main(args):
                          "kernel": "MSM stage (msm_glv_prep, msm_sort_lds, msm_seg_scan, msm_accumulate, msm_fixup, msm_window, msm_final_parts; both channels of every step of a launch)", "terms_per_launch": terms_total,
                          "algorithmic_bytes_per_launch": 96 * terms_total,
                          "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if isolated else "HIP events on the launch's stream, inside the timed region (other launches in flight)",
-                         "mean_stage_ms_timed_region": stages["msm"],
                          "kernels": kernels,
                          "alu": {"note": "the stage is bound by 32-bit integer multiply issue, not by HBM: achieved Fq products/s of the stage against the "
                                          "measured chip-wide peak of the Montgomery product (tools/limb29_microbench.hip)",
                                  "fq_products_per_term": 2 * 12 * 11, "fq_products_per_term_note": "2 GLV halves x 12 windows (c = 11, the 1024-proof step) x 11 per mixed addition",
                                  "achieved_Gprod_s": (2 * 12 * 11 * terms_total) / (msm_ms * 1e-3) / 1e9 if msm_ms > 0 else 0.0,
                                  "peak_Gprod_s": 168.0}},
-            "stages_ms": stages,
+            "stages_ms": isolated if isolated else stages,
+            "stages_ms_note": "HIP events between the stages, launches re-timed one at a time after the timed region (inside it only msm_accumulate is timed: an event between stages is a barrier packet, ~6 us of idle stream)",
             "stages_ms_one_launch_in_flight": isolated,
         }
         if m_re:

@@ -107,7 +107,7 @@ struct h2v_batch {
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
     uint32_t stream_words = 0;
     // profiling
-    bool profiling = false;
+    int profiling = 0;                // 0 off, 1: the dominant kernel's own events (msm_accumulate), 2: + an event between the stages
     hipEvent_t ev[8] = {nullptr};
     float last_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 };

@@ -132,7 +132,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     int rc;
     H2V_HIP_CHECK(hipMemsetAsync(b->fold_failed, 0, 4 * (size_t)G, s));   // set by h2v_batch_fold_check_enqueue only
     int ev = 0;
-    auto mark = [&]() { if (b->profiling) hipEventRecord(b->ev[ev], s); ++ev; };
+    auto mark = [&]() { if (b->profiling >= 2) hipEventRecord(b->ev[ev], s); ++ev; };   // (an event record is a barrier packet: ~6 us of idle stream each)
     mark();
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this launch (uploads) is visible to the auxiliary stream
     StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->ycanon, b->status, b->words, b->stream_words, b->chal};
@@ -183,7 +183,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
             pr.p.push_back(MsmProblem(b->msm_scal + first * 8, b->pts + first, b->acc + 2 * g + 1, 8, 1, gs * np,
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
         }
-        b->ws.profile = b->profiling; b->ws.profile_recorded = false;
+        b->ws.profile = b->profiling >= 1; b->ws.profile_recorded = false;
         // A launch that ends in its own pairing checks leaves the accumulators in pieces (MsmSplit): the checks take the pieces, the
         // whole points are put together beside them (close_enqueue).  Worth it while the launch is a latency chain, i.e. few groups.
         b->split = MsmSplit();
@@ -238,12 +238,15 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     const uint32_t* foldf = okv + G;
     const uint8_t* outb = b->results_host + 16 * (size_t)G;
     const int* st = reinterpret_cast<const int*>(b->results_host + 144 * (size_t)G);
-    if (b->profiling) {
+    for (int i = 0; i < 7; ++i) b->last_ms[i] = 0;
+    if (b->profiling >= 2) {
         // events: 0 start, 1 after decompression, 2 after transcript + multipliers, 3 after Fr program, 4 after fold, 5 after MSMs, 6 after pairing
         float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t45 = 0, t56 = 0;
         hipEventElapsedTime(&t01, b->ev[0], b->ev[1]); hipEventElapsedTime(&t12, b->ev[1], b->ev[2]); hipEventElapsedTime(&t23, b->ev[2], b->ev[3]);
         hipEventElapsedTime(&t34, b->ev[3], b->ev[4]); hipEventElapsedTime(&t45, b->ev[4], b->ev[5]); hipEventElapsedTime(&t56, b->ev[5], b->ev[6]);
         b->last_ms[0] = t01; b->last_ms[1] = t12; b->last_ms[2] = t23; b->last_ms[3] = t34; b->last_ms[4] = t45; b->last_ms[5] = t56;
+    }
+    if (b->profiling >= 1) {
         float tacc = 0;
         if (b->ws.profile_recorded) hipEventElapsedTime(&tacc, b->ws.ev_acc[0], b->ws.ev_acc[1]);
         b->last_ms[6] = tacc;
@@ -466,7 +469,7 @@ int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, 
     b->with_pairing = true;
     return 0;
 }
-int h2v_batch_set_profiling(h2v_batch* b, int enabled) { if (!b) return H2V_ERR_BAD_ARGUMENT; b->profiling = enabled != 0; return 0; }
+int h2v_batch_set_profiling(h2v_batch* b, int level) { if (!b) return H2V_ERR_BAD_ARGUMENT; b->profiling = level == 0 ? 0 : (level == H2V_PROFILE_KERNEL ? 1 : 2); return 0; }
 int h2v_batch_timings(h2v_batch* b, float* ms, int cap) {
     if (!b || !ms) return H2V_ERR_BAD_ARGUMENT;
     int k = cap < 7 ? cap : 7;

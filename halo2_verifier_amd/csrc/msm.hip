@@ -41,6 +41,7 @@
 // each, ~162 v_mad_u64_u32 per product), i.e. ~6 * 10^4 integer instructions per 96 bytes: the stage is bound by
 // 32-bit integer multiply issue, not by HBM (DESIGN.md "Roofline").
 #include "../../include/h2v.h"
+#include <hip/hip_ext.h>
 #include "batch.h"
 
 namespace h2v {
@@ -1004,9 +1005,12 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     // surplus is dispatched after they retire, ~7 ns each — the old bound (every term non-zero, shortest chunk) cost 9 500 empty
     // workgroups, 0.07 ms, at the end of every 20-step launch.
     const uint32_t acc_blocks = msm_accumulate_blocks(total_nz * 2 * p.windows);
-    if (ws.profile) hipEventRecord(ws.ev_acc[0], s);
-    hipLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor);
-    if (ws.profile) { hipEventRecord(ws.ev_acc[1], s); ws.profile_recorded = true; }
+    // (the profiling events are attached to the dispatch itself — its own start and stop timestamps — instead of being recorded around it:
+    // a recorded event is a barrier packet, ~6 us of idle stream on either side of the kernel)
+    if (ws.profile) {
+        hipExtLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.ev_acc[0], ws.ev_acc[1], 0, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor);
+        ws.profile_recorded = true;
+    } else hipLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64 + MSM_FIXUP_TEAM_BLOCKS), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {

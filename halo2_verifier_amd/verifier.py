@@ -441,8 +441,12 @@ class Batch:
         return ([bool(v) for v in ok], memoryview(st).cast('B').cast('i').tolist()[:self.n], [lr[64 * i:64 * i + 64] for i in range(g)],
                 [rr[64 * i:64 * i + 64] for i in range(g)])
 
+    PROFILE_KERNEL = 3   # H2V_PROFILE_KERNEL: the dominant kernel's own timestamps only
+
     def set_profiling(self, on=True):
-        check(self._lib.h2v_batch_set_profiling(self._h, 1 if on else 0))
+        """True / 1: an event between the stages and around the dominant kernel (each a barrier packet on the stream);
+        Batch.PROFILE_KERNEL: the dominant kernel's own timestamps only (no extra packet); False / 0: off"""
+        check(self._lib.h2v_batch_set_profiling(self._h, int(on)))
 
     def timings_ms(self):
         arr = (ctypes.c_float * len(self.STAGES))()

@@ -208,9 +208,13 @@ int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts
                    uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
 /* Per-stage device time of the last finished launch, milliseconds, measured with HIP events on
  * the batch's stream: [decompress, transcript, fr_program, fold, msm, pairing, msm_accumulate (the dominant kernel
- * inside the msm stage)]; returns the number of entries written (<= cap). */
+ * inside the msm stage)]; returns the number of entries written (<= cap).  Entries the profiling level does not record are 0. */
 int h2v_batch_timings(h2v_batch* b, float* ms, int cap);
-int h2v_batch_set_profiling(h2v_batch* b, int enabled);
+/* level 0: off; 1 (or any other non-zero value): an event between the stages and around the dominant kernel — every event is a
+ * barrier packet on the stream, ~6 us of idle time each, ~0.06 ms per launch; H2V_PROFILE_KERNEL: only the dominant kernel's own
+ * start / stop timestamps (attached to its dispatch, no extra packet). */
+#define H2V_PROFILE_KERNEL 3
+int h2v_batch_set_profiling(h2v_batch* b, int level);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,8 @@ pub const H2V_TRANSCRIPT_BLAKE2B: c_int = 0;
 pub const H2V_TRANSCRIPT_KECCAK256: c_int = 1;
 /// bytes one shard contributes per group to a sharded batch (two Jacobian points + failed-proof count)
 pub const H2V_ACC_RECORD_BYTES: usize = 224;
+/// h2v_batch_set_profiling: only the dominant kernel's own timestamps
+pub const H2V_PROFILE_KERNEL: c_int = 3;
 
 #[link(name = "h2v_amd")]
 extern "C" {
@@ -75,5 +77,5 @@ extern "C" {
     pub fn h2v_fold_check(ctx: *mut h2v_ctx, device_accumulators: *const c_void, n_parts: usize, ok: *mut c_int,
                           out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
     pub fn h2v_batch_timings(b: *mut h2v_batch, ms: *mut c_float, cap: c_int) -> c_int;
-    pub fn h2v_batch_set_profiling(b: *mut h2v_batch, enabled: c_int) -> c_int;
+    pub fn h2v_batch_set_profiling(b: *mut h2v_batch, level: c_int) -> c_int;
 }
