@@ -240,7 +240,7 @@ std::vector<uint32_t> pairing_program2() {
 struct Coef { Fq c0, c1, n1; };   // an Fq2 coefficient and the negated imaginary part: n1 = -c1
 struct alignas(16) PairShared {
     Fq2 line[N_LINES][6];         // per Miller step: the product of the step's line values, coefficients of w^0 .. w^5 (two lines: w^5 is zero)
-    Fq2 prod[36];                 // partial products a_i * b_j at [6 i + j]
+    Fq2 prod[37];                 // partial products a_i * b_j at [6 i + j]; [36] stays zero (fq12_fold)
     Coef reg[PAIR_REGS][6];
     uint32_t prog[PAIR_MAX_OPS];  // the operation table, copied once: one LDS broadcast read per operation instead of a memory load
 };
@@ -263,18 +263,17 @@ __device__ __forceinline__ void fq12_fold(const Fq2* prod, Coef* dst, uint32_t t
     const Fq2* e = &prod[k + 5 * first + (role == 0 ? 0 : 6)];
     const Fq* q = (im == same) ? &e->c1 : &e->c0;
     // a fixed six steps with the loads of all of them in flight at once (a loop over [first, last) waited for LDS every round;
-    // the lanes of a quad differ in their counts, so the wave ran the maximum anyway): entries outside the lane's range are masked
+    // the lanes of a quad differ in their counts, so the wave ran the maximum anyway): steps outside the lane's range read a zero entry
     uint32_t sum[9];
 #pragma unroll
     for (int l = 0; l < 9; ++l) sum[l] = 0;
     const uint32_t cnt = last > first ? last - first : 0;
-    if (!cnt) q = &prod[0].c0;                          // an idle lane reads a valid entry (masked)
+    const Fq* zero_entry = &prod[36].c0;               // entry 36 of every product array is kept at zero: steps beyond the lane's count read it
 #pragma unroll
     for (uint32_t ii = 0; ii < 6; ++ii) {
-        const Fq* qq = q + 10 * (ii < cnt ? ii : 0);   // 10 Fq = 5 entries
-        const uint32_t msk = ii < cnt ? 0xffffffffu : 0u;
+        const Fq* qq = ii < cnt ? q + 10 * ii : zero_entry;   // 10 Fq = 5 entries
 #pragma unroll
-        for (int l = 0; l < 9; ++l) sum[l] += qq->v[l] & msk;
+        for (int l = 0; l < 9; ++l) sum[l] += qq->v[l];
     }
     // partial products are < 1.05p: re = lo + 9 hs - ho + 6p in (0, 60p); im = lo + 9 hs + ho < 59p; -im = 60p - im
     int64_t acc[9];
@@ -398,6 +397,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
         s.reg[0][t] = c;
     }
     for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
+    if (t == 0) s.prod[36] = Fq2::zero();
     __syncthreads();
     for (uint32_t pc = 0; pc < n_ops; ++pc) {
         const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.prog[pc]);   // uniform: decoded on the scalar unit
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
 // products always come from k_pair_lines.
 struct alignas(16) PairShared2 {
     Fq2 line[PAIR_ITERS][6];
-    Fq2 prod[2][36];
+    Fq2 prod[2][37];              // [36] stays zero (fq12_fold)
     Coef reg[PAIR2_REGS][6];
     uint2 prog[PAIR2_MAX_STEPS];
 };
@@ -441,6 +441,7 @@ __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, co
         s.reg[t / 6][t % 6] = c;
     }
     for (uint32_t k = t; k < n_steps; k += 2 * PAIR_THREADS) s.prog[k] = prog[k];
+    if (tl == 0) s.prod[g][36] = Fq2::zero();
     __syncthreads();
     for (uint32_t pc = 0; pc < n_steps; ++pc) {
         const uint2 w2 = s.prog[pc];
@@ -469,7 +470,7 @@ __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, co
 struct PairIters { uint8_t first[PAIR_ITERS], cnt[PAIR_ITERS]; };   // iteration -> its lines in the context's tables
 struct PairLinesShared {
     Coef el0[PL_MAX_EL][6];                         // the tree's elements, ping-pong with u.el1
-    Fq2 prod[2][36];                                // partial products of the general products in flight
+    Fq2 prod[2][37];                                // partial products of the general products in flight; [36] stays zero (fq12_fold)
     union {
         struct { Coef ev[2 * PL_MAX_EL][3]; Fq2 sp[PL_MAX_EL][9]; } l;   // line values (w^0, w^1, w^3) and the sparse products A_u * B_v at [3 u + v]
         Coef el1[PL_MAX_EL][6];
@@ -479,6 +480,7 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
     __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     __shared__ PairLinesShared s;
     const uint32_t it = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
+    if (t < 2) s.prod[t][36] = Fq2::zero();   // read by fq12_fold; the first barrier below comes before any fold
     const uint32_t first = its.first[it], NP = S * its.cnt[it];   // sparse pair q = li * S + j: the lines (both sides) of piece j at line first + li
     // line leaf l = 2 q + side at the point ready[(2 chk + side) S + j] = (X Z, Y, Z^3): a Y + b (X Z) w + c Z^3 w^3.  Lane (l, k, component).
     for (uint32_t idx = t; idx < 2 * NP * 6; idx += PL_THREADS) {
