@@ -3,7 +3,7 @@
 
 One "step" = one pass of the whole hot path (point decompression -> Blake2b transcript -> Fr program -> shared-base fold
 -> pooled MSMs -> one pairing) over one batch of `--batch` proofs PER GPU that is already resident in HBM.  N > 1: every
-rank verifies its own shard, one 224-byte accumulator record per rank and step (2 G1 points + the shard's failed-proof
+rank verifies its own shard, one 1312-byte accumulator record per rank and step (the two accumulators in pieces + the shard's failed-proof
 count) is all-gathered over RCCL and folded, and a single pairing closes the whole N x batch step (weak scaling).
 The tail of a step — window Horner, the pairing — is a handful of waves with long dependent chains, so steps are issued
 `--groups` at a time as one grouped batch (h2v_batch_set_groups: every kernel runs once for all of them, each step keeps
@@ -285,13 +285,13 @@ def rank_main(args):
             b = batches[i]
             if uploads:
                 b.upload(uploads[i][0], 1024, uploads[i][1], [N_PUBLIC], uploads[i][2])
-            if world == 1:
+            if world == 1 and not os.environ.get("H2V_BENCH_FORCE_SHARDED"):   # (the knob runs the N > 1 call sequence on one GPU: what sharding costs besides the collective)
                 b.launch(with_pairing=True)
             else:
                 with torch.cuda.stream(streams[i]):
                     b.launch(with_pairing=False)
                     b.export_accumulators(acc_local[i].data_ptr())
-                    gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 224 B per rank
+                    gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 1312 B per rank
                     b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
             in_flight[i] = True
 

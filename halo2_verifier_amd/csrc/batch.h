@@ -103,6 +103,7 @@ struct h2v_batch {
     uint8_t* results = nullptr; uint8_t* results_host = nullptr; size_t results_bytes = 0;   // ok / fold_failed / out_ident / out_bytes / status live in `results`
     h2v::MsmWorkspace ws;
     h2v::MsmSplit split;              // how the last launch left its accumulators to the pairing (parts == 0: whole points in acc)
+    bool acc_stale = false;           // a launch without a pairing left pieces only: acc / out_bytes are put together on demand (ensure_whole)
     void* line_ws = nullptr; size_t line_ws_groups = 0;   // k_pair_lines' output, H2V_PAIRING_LINE_WS_BYTES per group
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
     uint32_t stream_words = 0;

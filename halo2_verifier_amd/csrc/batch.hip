@@ -117,6 +117,8 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
 }
 
 int close_enqueue(h2v_batch* b, bool with_pairing);
+int ensure_whole(h2v_batch* b);
+int export_batch_records(h2v_batch* b, void* device_dst);
 #define H2V_SPLIT_MAX_GROUPS 64u
 
 int launch_impl(h2v_batch* b, int with_pairing) {
@@ -184,12 +186,13 @@ int launch_impl(h2v_batch* b, int with_pairing) {
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
         }
         b->ws.profile = b->profiling >= 1; b->ws.profile_recorded = false;
-        // A launch that ends in its own pairing checks leaves the accumulators in pieces (MsmSplit): the checks take the pieces, the
-        // whole points are put together beside them (close_enqueue).  Worth it while the launch is a latency chain, i.e. few groups.
+        // A launch leaves the accumulators in pieces (MsmSplit): its own pairing checks take the pieces and the whole points are put
+        // together beside them (close_enqueue); a launch without a pairing (a shard) exports the pieces, the folded pairing takes them,
+        // and the whole points are only made if somebody reads them (ensure_whole).  Worth it while the launch is a latency chain, i.e. few groups.
         b->split = MsmSplit();
         const char* parts_env = getenv("H2V_MSM_PARTS");   // tuning / test knob, read per launch
         const uint32_t parts_knob = parts_env ? (uint32_t)atoi(parts_env) : MSM_MAX_PARTS;
-        if (with_pairing && n && G <= H2V_SPLIT_MAX_GROUPS && parts_knob > 1) {
+        if (n && G <= H2V_SPLIT_MAX_GROUPS && parts_knob > 1) {
             if (b->line_ws_groups < G) {
                 if (b->line_ws) { hipStreamSynchronize(s); hipFree(b->line_ws); b->line_ws = nullptr; b->line_ws_groups = 0; }
                 H2V_HIP_CHECK(hipMalloc(&b->line_ws, (size_t)G * H2V_PAIRING_LINE_WS_BYTES));
@@ -212,7 +215,11 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     hipStream_t s = b->stream;
     const uint32_t G = b->groups;
     int rc;
-    if (!with_pairing) return point_to_bytes_enqueue(s, b->acc, b->out_bytes, b->out_ident, 2 * G);
+    b->acc_stale = false;
+    if (!with_pairing) {
+        if (b->split.parts) { b->acc_stale = true; return 0; }   // pieces only for now
+        return point_to_bytes_enqueue(s, b->acc, b->out_bytes, b->out_ident, 2 * G);
+    }
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork, s));
     H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
     if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split))) return rc;   // acc <- the whole points
@@ -223,6 +230,20 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join, 0));
     return 0;
 }
+// the whole accumulators (acc) and their affine bytes, if the last launch left pieces only
+int ensure_whole(h2v_batch* b) {
+    if (!b->acc_stale) return 0;
+    int rc;
+    if ((rc = msm_combine_enqueue(b->stream, b->ws, b->split))) return rc;
+    if ((rc = point_to_bytes_enqueue(b->stream, b->acc, b->out_bytes, b->out_ident, 2 * b->groups))) return rc;
+    b->acc_stale = false;
+    return 0;
+}
+// the batch's accumulator records (pieces if the launch left pieces)
+int export_batch_records(h2v_batch* b, void* device_dst) {
+    if (b->split.parts) return export_records_enqueue(b->stream, nullptr, b->split.pts, b->split.parts, b->split.shift, b->status, b->n, b->groups, device_dst);
+    return export_records_enqueue(b->stream, b->acc, nullptr, 1, 0, b->status, b->n, b->groups, device_dst);
+}
 
 // group_ok / out_left / out_right hold one entry (64 bytes) per group
 int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left, uint8_t* out_right) {
@@ -230,6 +251,7 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     hipStream_t s = b->stream;
     const uint32_t n = b->n, G = b->groups, gs = n / G;
+    { int rcw = ensure_whole(b); if (rcw) return rcw; }
     const size_t nbytes = 144 * (size_t)G + 4 * (size_t)n;
     H2V_HIP_CHECK(hipMemcpyAsync(b->results_host, b->results, nbytes, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
@@ -440,6 +462,7 @@ int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, 
 }
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes) {
     if (!b || !b->acc || !device_ptr) { set_last_error("h2v_batch_accumulators: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
+    if (b->launched) { H2V_HIP_CHECK(hipSetDevice(b->ctx->device)); int rcw = ensure_whole(b); if (rcw) return rcw; }
     *device_ptr = b->acc;
     if (nbytes) *nbytes = 2 * sizeof(G1J) * b->groups;   // raw points, no failure word: see h2v_batch_export_accumulators
     return 0;
@@ -456,15 +479,19 @@ int h2v_batch_set_stream(h2v_batch* b, void* hip_stream) {
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst) {
     if (!b || !b->launched || !device_dst) { set_last_error("h2v_batch_export_accumulators: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
-    return export_records_enqueue(b->stream, b->acc, b->status, b->n, b->groups, device_dst);
+    return export_batch_records(b, device_dst);
 }
 int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, size_t n_parts) {
     if (!b || !b->launched || !device_accumulators || !n_parts) { set_last_error("h2v_batch_fold_check_enqueue: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     int rc;
     const uint32_t G = b->groups;
-    if ((rc = fold_records_enqueue(b->stream, device_accumulators, (uint32_t)n_parts, G, b->acc, b->fold_failed))) return rc;
-    b->split = MsmSplit();   // the folded accumulators are whole points
+    // the fold keeps the cut of this rank's own launch: records cut the same way add up piece by piece, the pairing takes the pieces
+    // (the folded pieces replace the rank's own in the workspace: they were exported before the collective that brought these records)
+    if (b->split.parts) {
+        G1JSlot* pieces = b->ws.pieces; G1JSlot* ready = b->ws.pieces + (size_t)MSM_MAX_PARTS * b->ws.cap_problems;
+        if ((rc = fold_records_enqueue(b->stream, device_accumulators, (uint32_t)n_parts, G, b->split.parts, b->split.shift, b->acc, pieces, ready, b->fold_failed))) return rc;
+    } else if ((rc = fold_records_enqueue(b->stream, device_accumulators, (uint32_t)n_parts, G, 1, 0, b->acc, nullptr, nullptr, b->fold_failed))) return rc;
     if ((rc = close_enqueue(b, true))) return rc;
     b->with_pairing = true;
     return 0;
@@ -486,7 +513,7 @@ int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts
     int rc;
     if ((rc = acc.alloc(2)) || (rc = d_ok.alloc(1)) || (rc = d_out.alloc(128)) || (rc = d_ident.alloc(2)) || (rc = d_failed.alloc(1))) return rc;
     uint32_t okv = 0, failed = 0; uint8_t outb[128];
-    if ((rc = fold_records_enqueue(s, device_accumulators, (uint32_t)n_parts, 1, acc.p, d_failed.p))) return rc;
+    if ((rc = fold_records_enqueue(s, device_accumulators, (uint32_t)n_parts, 1, 1, 0, acc.p, nullptr, nullptr, d_failed.p))) return rc;   // whole points: records in pieces are put together
     if ((rc = pairing_check_enqueue(s, ctx->pairing, acc.p, 1, d_ok.p))) return rc;
     if ((rc = point_to_bytes_enqueue(s, acc.p, d_out.p, d_ident.p, 2))) return rc;
     H2V_HIP_CHECK(hipMemcpyAsync(&okv, d_ok.p, 4, hipMemcpyDeviceToHost, s));
@@ -562,7 +589,7 @@ int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs
             if ((rc = upload_impl(b, m, flat.data(), pl.proof_len, iflat.data(), nc, groups[gi].first.data(), ones.data(), m))) break;
             b->ext_mult = d_mult.p; b->ext_idx = d_idx.p + idx_off;
             if ((rc = launch_impl(b, 0))) break;
-            if ((rc = export_records_enqueue(b->stream, b->acc, b->status, b->n, 1, d_records.p + gi * H2V_ACC_RECORD_BYTES))) break;
+            if ((rc = export_batch_records(b, d_records.p + gi * H2V_ACC_RECORD_BYTES))) break;
             if ((rc = finish_impl(b, st.data(), &gok, nullptr, nullptr))) break;
         } while (0);
         h2v_batch_destroy(b);

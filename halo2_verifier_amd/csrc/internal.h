@@ -124,10 +124,13 @@ int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, 
 int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
 // Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n);
-// Sharded batches exchange H2V_ACC_RECORD_BYTES records per group: [left G1J][right G1J][u32 failed proofs][u32 0].
-// export: d_out[g] <- (acc[2g], acc[2g+1], number of non-zero statuses among the group's n / groups proofs)
-int export_records_enqueue(hipStream_t s, const G1J* d_acc, const int* d_status, uint32_t n, uint32_t groups, void* d_out);
-// fold: acc[2g + c] = sum over parts i of record [i][g]'s channel c; d_fold_failed[g] = sum of the records' failure counts
-int fold_records_enqueue(hipStream_t s, const void* d_parts, uint32_t n_parts, uint32_t groups, G1J* d_acc, uint32_t* d_fold_failed);
+// Sharded batches exchange H2V_ACC_RECORD_BYTES records per group: [failed, parts, shift, 0][left pieces][right pieces] (h2v.h).
+// export: d_out[g] <- the group's accumulators — pieces [(2g + side) * parts + j] if d_pieces, else the whole points d_acc[2g], [2g+1] —
+// and the number of non-zero statuses among the group's n / groups proofs
+int export_records_enqueue(hipStream_t s, const G1J* d_acc, const G1JSlot* d_pieces, uint32_t parts, uint32_t shift, const int* d_status, uint32_t n, uint32_t groups, void* d_out);
+// fold: the sums over the records [i][g] of each group's accumulators, cut into `parts` pieces of weight 2^(shift j) (-> d_pieces and,
+// as (X Z, Y, Z^3), d_ready) or whole (parts <= 1 -> d_acc[2g + side]); d_fold_failed[g] = sum of the records' failure counts
+int fold_records_enqueue(hipStream_t s, const void* d_recs, uint32_t n_recs, uint32_t groups, uint32_t parts, uint32_t shift, G1J* d_acc, G1JSlot* d_pieces, G1JSlot* d_ready,
+                         uint32_t* d_fold_failed);
 
 }  // namespace h2v

@@ -40,12 +40,16 @@ __global__ void k_point_to_bytes(const G1J* __restrict__ in, uint8_t* __restrict
     for (int j = 0; j < 64; ++j) out[64 * (size_t)i + j] = tmp[j];
 }
 
-// The record a rank contributes to a sharded batch (include/h2v.h H2V_ACC_RECORD_BYTES): the two accumulator points of one
-// group plus the number of the shard's proofs that failed before the MSM.  A failed proof is zeroed out of its shard's
-// accumulators, so without the flag every OTHER rank's folded pairing would still pass.
-struct AccRecord { G1J left, right; uint32_t failed, reserved; };
-static_assert(sizeof(AccRecord) == H2V_ACC_RECORD_BYTES, "accumulator record layout");
-__global__ void __launch_bounds__(256) k_export_records(const G1J* __restrict__ acc, const int* __restrict__ status, uint32_t gs, AccRecord* __restrict__ out) {
+// The record a rank contributes to a sharded batch (include/h2v.h H2V_ACC_RECORD_BYTES): the two accumulators of one group —
+// in the pieces the launch left them in (MsmSplit), or whole (parts = 1) — plus the number of the shard's proofs that failed
+// before the MSM.  A failed proof is zeroed out of its shard's accumulators, so without the count every OTHER rank's folded
+// pairing would still pass.
+struct AccRecord { uint32_t failed, parts, shift, reserved; G1J left[H2V_ACC_RECORD_PIECES], right[H2V_ACC_RECORD_PIECES]; };
+static_assert(sizeof(AccRecord) == H2V_ACC_RECORD_BYTES && H2V_ACC_RECORD_BYTES == 16 + 2 * H2V_ACC_RECORD_PIECES * 108, "accumulator record layout");
+static_assert(H2V_ACC_RECORD_PIECES >= MSM_MAX_PARTS, "a record holds every piece a launch can leave");
+// acc: whole points [2g], [2g+1] (parts == 1) — or pieces: [(2g + side) * parts + j]
+__global__ void __launch_bounds__(256) k_export_records(const G1J* __restrict__ acc, const G1JSlot* __restrict__ pieces, uint32_t parts, uint32_t shift,
+                                                        const int* __restrict__ status, uint32_t gs, AccRecord* __restrict__ out) {
     __shared__ uint32_t failed;
     const uint32_t g = blockIdx.x, t = threadIdx.x;
     if (t == 0) failed = 0;
@@ -54,30 +58,61 @@ __global__ void __launch_bounds__(256) k_export_records(const G1J* __restrict__ 
     for (uint32_t p = t; p < gs; p += 256) mine += status[(size_t)g * gs + p] != 0 ? 1u : 0u;
     if (mine) atomicAdd(&failed, mine);
     __syncthreads();
-    if (t == 0) { out[g].left = acc[2 * g]; out[g].right = acc[2 * g + 1]; out[g].failed = failed; out[g].reserved = 0; }
+    if (t < 2 * H2V_ACC_RECORD_PIECES) {
+        const uint32_t side = t / H2V_ACC_RECORD_PIECES, j = t % H2V_ACC_RECORD_PIECES;
+        G1J v = G1J::identity();
+        if (j < parts) v = pieces ? pieces[(size_t)(2 * g + side) * parts + j].p : acc[2 * g + side];
+        (side ? out[g].right : out[g].left)[j] = v;
+    }
+    if (t == 0) { out[g].failed = failed; out[g].parts = parts; out[g].shift = shift; out[g].reserved = 0; }
 }
-// acc[2g], acc[2g+1] = sum over parts of the group's left / right points; fold_failed[g] = total failed proofs over all parts
-__global__ void k_fold_records(const AccRecord* __restrict__ parts, uint32_t n_parts, uint32_t groups, G1J* __restrict__ acc, uint32_t* __restrict__ fold_failed) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;  // even: a left channel, odd: a right channel
-    if (k >= 2 * groups) return;
-    const uint32_t g = k >> 1;
+// a record's accumulator put together: sum_j 2^(shift j) piece_j (only for records that do not match the fold's own split: rare)
+__device__ __noinline__ G1J acc_record_whole(const G1J* pc, uint32_t parts, uint32_t shift) {
+    if (parts == 0) return G1J::identity();
+    G1J a = pc[parts - 1];
+    for (uint32_t j = parts - 1; j-- > 0;) {
+        for (uint32_t i = 0; i < shift; ++i) a = g1_add(a, a);
+        a = g1_add(a, pc[j]);
+    }
+    return a;
+}
+// Fold: piece j of (group g, side) = sum over the ranks' records of their piece j — records that were cut the same way
+// (parts, shift) add up piece by piece; a record cut differently is put together first and joins piece 0, whose weight is 1.
+// parts == 1: the result is the whole point, written to acc[2g + side]; else to pieces[(2g + side) * parts + j] and, in the form
+// the Miller lines are evaluated at (X Z, Y, Z^3), to ready[...].  fold_failed[g] = total failed proofs over all records.
+__global__ void __launch_bounds__(64) k_fold_records(const AccRecord* __restrict__ recs, uint32_t n_recs, uint32_t groups, uint32_t parts, uint32_t shift,
+                                                     G1J* __restrict__ acc, G1JSlot* __restrict__ pieces, G1JSlot* __restrict__ ready, uint32_t* __restrict__ fold_failed) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * groups * parts) return;
+    const uint32_t j = k % parts, gs2 = k / parts, g = gs2 >> 1, side = gs2 & 1u;
     G1J sum = G1J::identity();
     uint32_t failed = 0;
-    for (uint32_t i = 0; i < n_parts; ++i) {
-        const AccRecord& r = parts[(size_t)i * groups + g];
-        sum = g1_add(sum, (k & 1) ? r.right : r.left);
+    for (uint32_t i = 0; i < n_recs; ++i) {
+        const AccRecord& r = recs[(size_t)i * groups + g];
+        const G1J* pc = side ? r.right : r.left;
+        const bool same = r.parts == parts && (r.shift == shift || parts == 1) && r.parts <= H2V_ACC_RECORD_PIECES;
+        if (same) sum = g1_add(sum, pc[j]);
+        else if (j == 0) sum = g1_add(sum, acc_record_whole(pc, r.parts <= H2V_ACC_RECORD_PIECES ? r.parts : 0u, r.shift));
         failed += r.failed;
     }
-    acc[k] = sum;
-    if (!(k & 1)) fold_failed[g] = failed;
+    if (parts == 1) acc[gs2] = sum;
+    else {
+        pieces[k] = sum;
+        G1J rd; rd.X = sum.X * sum.Z; rd.Y = sum.Y; rd.Z = sum.Z.sqr() * sum.Z;
+        ready[k] = rd;
+    }
+    if (j == 0 && side == 0) fold_failed[g] = failed;
 }
-int export_records_enqueue(hipStream_t s, const G1J* d_acc, const int* d_status, uint32_t n, uint32_t groups, void* d_out) {
-    hipLaunchKernelGGL(k_export_records, dim3(groups), dim3(256), 0, s, d_acc, d_status, n / groups, (AccRecord*)d_out);
+int export_records_enqueue(hipStream_t s, const G1J* d_acc, const G1JSlot* d_pieces, uint32_t parts, uint32_t shift, const int* d_status, uint32_t n, uint32_t groups, void* d_out) {
+    if (!d_pieces) { parts = 1; shift = 0; }
+    hipLaunchKernelGGL(k_export_records, dim3(groups), dim3(256), 0, s, d_acc, d_pieces, parts, shift, d_status, n / groups, (AccRecord*)d_out);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int fold_records_enqueue(hipStream_t s, const void* d_parts, uint32_t n_parts, uint32_t groups, G1J* d_acc, uint32_t* d_fold_failed) {
-    hipLaunchKernelGGL(k_fold_records, dim3((2 * groups + 63) / 64), dim3(64), 0, s, (const AccRecord*)d_parts, n_parts, groups, d_acc, d_fold_failed);
+int fold_records_enqueue(hipStream_t s, const void* d_recs, uint32_t n_recs, uint32_t groups, uint32_t parts, uint32_t shift, G1J* d_acc, G1JSlot* d_pieces, G1JSlot* d_ready,
+                         uint32_t* d_fold_failed) {
+    if (parts <= 1 || !d_pieces) { parts = 1; shift = 0; }
+    hipLaunchKernelGGL(k_fold_records, dim3((2 * groups * parts + 63) / 64), dim3(64), 0, s, (const AccRecord*)d_recs, n_recs, groups, parts, shift, d_acc, d_pieces, d_ready, d_fold_failed);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -2,8 +2,10 @@
 
 The reference has no communication layer.  Proofs are independent until the final
 pairing, so the batch is cut into contiguous shards; every rank runs the whole per-proof pipeline
-and its two pooled MSMs, and the only exchange is an all-gather of one 224-byte record per rank and group (2 G1 points of 108 bytes + the shard's failed-proof count) — RCCL has no user-defined reduction, and a group addition is not a numeric sum — followed
-by a 2(N-1)-addition fold and ONE pairing (DualMSM::add_msm + check, poly/kzg/msm.rs:178-203).
+and its two pooled MSMs, and the only exchange is an all-gather of one 1312-byte record per rank and group (the two accumulators in
+the six pieces the launch leaves them in, 108 bytes each, + the shard's failed-proof count) — RCCL has no user-defined reduction, and
+a group addition is not a numeric sum — followed by a piece-wise fold and ONE pairing over the pieces (DualMSM::add_msm + check,
+poly/kzg/msm.rs:178-203).
 
 Multipliers: proof i of the whole batch is scaled by the product of the Fr::random draws of all
 later proofs (kzg/strategy.rs:129, msm.rs:173-176), indexed globally, so the result does not
@@ -18,10 +20,10 @@ def shard_bounds(total: int, world_size: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-# include/h2v.h H2V_ACC_RECORD_BYTES: 2 x Jacobian G1 (3 coordinates x 9 limbs x 4 B, the library's Montgomery limb layout)
-# + u32 count of the shard's failed proofs + u32 zero.  The count travels with the points so that every rank clears the
-# verdict when ANY shard rejected a proof (a failed proof contributes nothing to its shard's accumulators).
-ACC_BYTES = 224
+# include/h2v.h H2V_ACC_RECORD_BYTES: [u32 failed proofs of the shard][u32 parts][u32 shift][u32 0] + 2 x 6 Jacobian G1 pieces
+# (3 coordinates x 9 limbs x 4 B, the library's Montgomery limb layout).  The count travels with the points so that every rank
+# clears the verdict when ANY shard rejected a proof (a failed proof contributes nothing to its shard's accumulators).
+ACC_BYTES = 16 + 2 * 6 * 108
 
 
 def gather_accumulators(local_acc, world_size, group=None):

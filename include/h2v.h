@@ -182,12 +182,19 @@ int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, 
  * (X, Y, Z) in the library's Montgomery limb layout (debug / inspection; the record a sharded run exchanges is written by
  * h2v_batch_export_accumulators). */
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes);
-/* What a shard contributes to a sharded batch, per group: [left point 108 B][right point 108 B][u32 number of this shard's
- * proofs with a non-zero status][u32 0] — opaque bytes to be moved by a collective (all-gather).  The failure count matters:
- * a failed proof is zeroed out of its shard's accumulators, so the folded pairing alone would accept a batch in which another
- * shard rejected a proof; h2v_batch_fold_check_enqueue / h2v_fold_check clear `ok` when any folded record reports failures,
- * so every rank reaches the same verdict without a second collective. */
-#define H2V_ACC_RECORD_BYTES 224
+/* What a shard contributes to a sharded batch, per group — opaque bytes to be moved by a collective (all-gather):
+ *   [u32 failed][u32 parts][u32 shift][u32 0][left piece 0 .. 5][right piece 0 .. 5]      (a piece: 108 B, Jacobian X, Y, Z)
+ * `failed` = number of this shard's proofs with a non-zero status.  It matters: a failed proof is zeroed out of its shard's
+ * accumulators, so the folded pairing alone would accept a batch in which another shard rejected a proof;
+ * h2v_batch_fold_check_enqueue / h2v_fold_check clear `ok` when any folded record reports failures, so every rank reaches the same
+ * verdict without a second collective.
+ * The accumulators travel the way a launch leaves them — in `parts` pieces, accumulator = sum_j 2^(shift j) piece_j — because the
+ * folded pairing takes them in pieces too (the doublings move to precomputed multiples of the two G2 points; the whole point would
+ * cost ~120 dependent doublings on every rank before AND the slower pairing after the exchange).  parts = 1, shift = 0 is a whole
+ * point.  Records of ranks whose launches chose another (parts, shift) — shards of very different size — are folded correctly all
+ * the same (their pieces are put together first). */
+#define H2V_ACC_RECORD_PIECES 6
+#define H2V_ACC_RECORD_BYTES 1312   /* 16 + 2 * H2V_ACC_RECORD_PIECES * 108 */
 /* The HIP stream (hipStream_t) the batch runs on, for event timing and stream-ordered interop. */
 void* h2v_batch_stream(h2v_batch* b);
 /* Run the batch on a caller-owned stream (e.g. a torch.cuda.Stream's cuda_stream) instead of its own,

@@ -30,8 +30,10 @@ pub const H2V_MULTIOPEN_SHPLONK: c_int = 0;
 pub const H2V_MULTIOPEN_GWC: c_int = 1;
 pub const H2V_TRANSCRIPT_BLAKE2B: c_int = 0;
 pub const H2V_TRANSCRIPT_KECCAK256: c_int = 1;
-/// bytes one shard contributes per group to a sharded batch (two Jacobian points + failed-proof count)
-pub const H2V_ACC_RECORD_BYTES: usize = 224;
+/// accumulator pieces per side in a record
+pub const H2V_ACC_RECORD_PIECES: usize = 6;
+/// bytes one shard contributes per group to a sharded batch ([failed, parts, shift, 0] + 2 x 6 Jacobian pieces)
+pub const H2V_ACC_RECORD_BYTES: usize = 1312;
 /// h2v_batch_set_profiling: only the dominant kernel's own timestamps
 pub const H2V_PROFILE_KERNEL: c_int = 3;
 
