@@ -140,8 +140,8 @@ H2V_FN G1A g1_to_affine(const G1J& p) {
 // The exponent is a constant, so the whole sliding-window schedule (which odd power multiplies in after which run of
 // squarings) is computed at compile time and the loop below unrolls into straight-line calls: the table of odd powers
 // is indexed by constants only and stays in registers — a run-time-indexed table would live in scratch memory.
-struct FqSqrtSchedule { uint8_t op[300]; int n; };  // 0: square; k > 0: multiply by a^(2k-1)
-constexpr FqSqrtSchedule fq_sqrt_schedule() {
+struct FqSqrtSchedule { uint8_t op[400]; int n; };  // 0: square; k > 0: multiply by a^(2k-1)
+template <int W> constexpr FqSqrtSchedule fq_sqrt_schedule() {   // sliding windows of at most W bits
     // (p+1)/4 = 0x0c19139cb84c680a6e14116da060561765e05aa45a1c72a34f082305b61f3f52
     constexpr uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
     FqSqrtSchedule s{};
@@ -150,7 +150,7 @@ constexpr FqSqrtSchedule fq_sqrt_schedule() {
     while (i >= 0 && !((e[i >> 5] >> (i & 31)) & 1)) --i;
     while (i >= 0) {
         if (!((e[i >> 5] >> (i & 31)) & 1)) { s.op[s.n++] = 0; --i; continue; }
-        int l = i - 3 < 0 ? 0 : i - 3;                       // window of at most 4 bits ending in a set bit
+        int l = i - (W - 1) < 0 ? 0 : i - (W - 1);           // window of at most W bits ending in a set bit
         while (!((e[l >> 5] >> (l & 31)) & 1)) ++l;
         uint32_t v = 0;
         for (int k = i; k >= l; --k) { v = (v << 1) | ((e[k >> 5] >> (k & 31)) & 1); s.op[s.n++] = 0; }
@@ -159,13 +159,16 @@ constexpr FqSqrtSchedule fq_sqrt_schedule() {
     }
     return s;
 }
-H2V_FN Fq fq_sqrt_candidate(const Fq& a) {
-    constexpr FqSqrtSchedule S = fq_sqrt_schedule();
-    Fq t[8];
+// W = 3 (a table of four odd powers: 36 registers instead of 72, ten more products in ~320) is what the decompression kernel
+// uses: at its four waves per SIMD the 4-bit table did not fit the 128-register budget and spilled
+template <int W> __host__ __device__ inline __attribute__((noinline)) Fq fq_sqrt_candidate_w(const Fq& a) {
+    constexpr FqSqrtSchedule S = fq_sqrt_schedule<W>();
+    constexpr int T = 1 << (W - 1);
+    Fq t[T];
     t[0] = a;
     const Fq a2 = a.sqr();
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t[k] = t[k - 1] * a2;
+    for (int k = 1; k < T; ++k) t[k] = t[k - 1] * a2;
     Fq r = Fq::one();
     bool started = false;  // squarings of the leading 1 are skipped (resolved at compile time once unrolled)
 #pragma unroll
@@ -175,6 +178,7 @@ H2V_FN Fq fq_sqrt_candidate(const Fq& a) {
     }
     return r;
 }
+H2V_FN Fq fq_sqrt_candidate(const Fq& a) { return fq_sqrt_candidate_w<4>(a); }
 
 // G1Affine::from_bytes (compressed).  Returns false for an invalid encoding.
 H2V_FN bool g1_decompress(const uint8_t in[32], G1A& out) {
