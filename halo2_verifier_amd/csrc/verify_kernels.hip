@@ -625,7 +625,7 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     // latency chain), so the budget follows the number of workgroups: the whole 160 KB of a CU while there are at most 256,
     // half of it up to 384.
     const uint32_t waves = (a.n + 63) / 64;
-    static const bool one_stream = getenv("H2V_FRVM_ONE_STREAM") != nullptr;
+    const bool one_stream = getenv("H2V_FRVM_ONE_STREAM") != nullptr;   // knob, read per call: tests switch it
     const bool two = a.code2[0] && a.code2[1] && a.n_code2[0] && a.n_code2[1] && !one_stream;
     if (two) n_slots = a.n_slots2;
     // (a launch with more workgroups than that is a throughput launch — several of them are in flight — and an LDS-hungry kernel keeps

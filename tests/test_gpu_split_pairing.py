@@ -127,3 +127,48 @@ def test_gwc_plan_has_its_own_shift():
             assert ctx.verify_batch(P, I, rand) == exp, parts
     ctx.close()
     s.free()
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("knobs", [dict(H2V_PAIRING_ONE_STREAM="1"), dict(H2V_FRVM_ONE_STREAM="1"), dict(H2V_PAIRING_ONE_STREAM="1", H2V_FRVM_ONE_STREAM="1"),
+                                   dict(H2V_MSM_GLOBAL_SORT="1"), dict(H2V_MSM_PARTS="1", H2V_FRVM_ONE_STREAM="1")])
+def test_single_stream_and_fallback_kernels_stay_exact(pool, knobs):
+    """The default path runs the Fr program and the pairing as two instruction streams each and sorts inside LDS; the single-stream
+    interpreter, the single-stream pairing table over merged lines, the whole-point pairing and the global counting sort remain in
+    the library (other launch shapes, knobs) — same verdicts, statuses and accumulator bytes as the oracle through every one."""
+    s, P, I = pool
+    n = 40
+    rnd = random.Random(11)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    I_bad = list(I[:n]); I_bad[3] = [[circuits.le32(8)] + I[3][0][1:]]
+    P_rej = list(P[:n]); b = bytearray(P_rej[17]); b[40] ^= 0x55; P_rej[17] = bytes(b)
+    exp = circuits.oracle_verify_batch(s, P[:n], I[:n], rand)
+    exp_bad = circuits.oracle_verify_batch(s, P[:n], I_bad, rand)
+    exp_rej = circuits.oracle_verify_batch(s, P_rej, I[:n], rand)
+    assert exp[0] is True and exp_bad[0] is False
+    ctx = _ctx(s)
+    with _env(**knobs):
+        assert ctx.verify_batch(P[:n], I[:n], rand) == exp
+        assert ctx.verify_batch(P[:n], I_bad, rand) == exp_bad
+        assert ctx.verify_batch(P_rej, I[:n], rand) == exp_rej
+        assert ctx.verify_each(P[:6], I_bad[:6]) == [0, 0, 0, -2, 0, 0]
+    ctx.close()
