@@ -613,7 +613,12 @@ __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restric
         const uint32_t qn = b_next / nbq;
         MsmProblem q_next = q;
         if (qn != qi) q_next = prs[qn];
-        if (pos < chunk_hi) { e_next = list[(size_t)sg * g.stride + (pos - seg_lo)]; raw_next = msm_entry_load(q_next, e_next); }
+        // (unconditional: behind the chunk's last entry the same entry is loaded once more — inside an `if` the compiler waited for the
+        // loads at the end of the block, i.e. BEFORE the addition they were meant to overlap.  Measured: 0.865 -> 0.857 ms; fetching the
+        // list entry two iterations ahead as well, so that no iteration waits for a dependent pair of loads: no further change — the
+        // second wave of the SIMD already covers these stalls)
+        const uint32_t pos_n = min(pos, chunk_hi - 1);
+        e_next = list[(size_t)sg * g.stride + (pos_n - seg_lo)]; raw_next = msm_entry_load(q_next, e_next);
         ok = g1_madd_fast(acc, msm_entry_apply(raw, e));
         if (flush) {
             if (ok) *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
