@@ -82,19 +82,31 @@ __device__ __noinline__ G1J acc_record_whole(const G1J* pc, uint32_t parts, uint
 // the Miller lines are evaluated at (X Z, Y, Z^3), to ready[...].  fold_failed[g] = total failed proofs over all records.
 __global__ void __launch_bounds__(64) k_fold_records(const AccRecord* __restrict__ recs, uint32_t n_recs, uint32_t groups, uint32_t parts, uint32_t shift,
                                                      G1J* __restrict__ acc, G1JSlot* __restrict__ pieces, G1JSlot* __restrict__ ready, uint32_t* __restrict__ fold_failed) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= 2 * groups * parts) return;
-    const uint32_t j = k % parts, gs2 = k / parts, g = gs2 >> 1, side = gs2 & 1u;
+    // a team of eight lanes per output point: lane r adds the records r, r + 8, ..., then a three-level butterfly — the sum over the
+    // ranks is on the critical path of every sharded launch (eight ranks: 4 dependent additions instead of 8)
+    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, r = threadIdx.x & 7u;
+    const bool live = k < 2 * groups * parts;
+    const uint32_t j = live ? k % parts : 0, gs2 = live ? k / parts : 0, g = gs2 >> 1, side = gs2 & 1u;
     G1J sum = G1J::identity();
     uint32_t failed = 0;
-    for (uint32_t i = 0; i < n_recs; ++i) {
-        const AccRecord& r = recs[(size_t)i * groups + g];
-        const G1J* pc = side ? r.right : r.left;
-        const bool same = r.parts == parts && (r.shift == shift || parts == 1) && r.parts <= H2V_ACC_RECORD_PIECES;
+    if (live) for (uint32_t i = r; i < n_recs; i += 8) {
+        const AccRecord& rec = recs[(size_t)i * groups + g];
+        const G1J* pc = side ? rec.right : rec.left;
+        const bool same = rec.parts == parts && (rec.shift == shift || parts == 1) && rec.parts <= H2V_ACC_RECORD_PIECES;
         if (same) sum = g1_add(sum, pc[j]);
-        else if (j == 0) sum = g1_add(sum, acc_record_whole(pc, r.parts <= H2V_ACC_RECORD_PIECES ? r.parts : 0u, r.shift));
-        failed += r.failed;
+        else if (j == 0) sum = g1_add(sum, acc_record_whole(pc, rec.parts <= H2V_ACC_RECORD_PIECES ? rec.parts : 0u, rec.shift));
+        failed += rec.failed;
     }
+    for (uint32_t d = 4; d > 0; d >>= 1) {
+        G1J other;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&sum);
+#pragma unroll
+        for (uint32_t w = 0; w < sizeof(G1J) / 4; ++w) dst[w] = (uint32_t)__shfl_down((int)src[w], d, 8);
+        sum = g1_add(sum, other);   // lanes r >= 8 - d add a value they do not own: only r = 0 is kept
+        failed += (uint32_t)__shfl_down((int)failed, d, 8);
+    }
+    if (!live || r) return;
     if (parts == 1) acc[gs2] = sum;
     else {
         pieces[k] = sum;
@@ -112,7 +124,7 @@ int export_records_enqueue(hipStream_t s, const G1J* d_acc, const G1JSlot* d_pie
 int fold_records_enqueue(hipStream_t s, const void* d_recs, uint32_t n_recs, uint32_t groups, uint32_t parts, uint32_t shift, G1J* d_acc, G1JSlot* d_pieces, G1JSlot* d_ready,
                          uint32_t* d_fold_failed) {
     if (parts <= 1 || !d_pieces) { parts = 1; shift = 0; }
-    hipLaunchKernelGGL(k_fold_records, dim3((2 * groups * parts + 63) / 64), dim3(64), 0, s, (const AccRecord*)d_recs, n_recs, groups, parts, shift, d_acc, d_pieces, d_ready, d_fold_failed);
+    hipLaunchKernelGGL(k_fold_records, dim3((8 * 2 * groups * parts + 63) / 64), dim3(64), 0, s, (const AccRecord*)d_recs, n_recs, groups, parts, shift, d_acc, d_pieces, d_ready, d_fold_failed);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
