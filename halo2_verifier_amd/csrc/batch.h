@@ -28,7 +28,7 @@ inline int status_decode(int dev) {
 }
 
 struct FrvmArgs {
-    const VmInstr* code; uint32_t n_code;   // one stream (k_frvm), or stream 0 of two (k_frvm2: code2 != nullptr)
+    const VmInstr* code; uint32_t n_code;   // the program as ONE stream (k_frvm)
     const Fr* consts;
     Fr* slots;
     uint32_t n;
@@ -41,8 +41,9 @@ struct FrvmArgs {
     uint32_t* left_scal;
     const Fr* insteval;   // [query][proof], wide instance vectors only
     uint32_t* guard_scal; uint32_t n_guard;   // [proof][term][8], guard variant of a GWC plan only (h2v_guard_msm)
-    // the same program as two instruction streams per proof (k_frvm2; slot numbering of its own): frvm_enqueue chooses
-    const VmInstr* code2[2] = {nullptr, nullptr}; uint32_t n_code2[2] = {0, 0}; uint32_t n_slots2 = 0;
+    // the same program as 2 / 3 / 4 instruction streams per proof (k_frvm2; index K - 2, slot numbering of its own): frvm_enqueue chooses
+    const VmInstr* code_k[3][FRVM_MAX_STREAMS] = {{nullptr}}; uint32_t n_code_k[3][FRVM_MAX_STREAMS] = {{0}}; uint32_t n_slots_k[3] = {0, 0, 0};
+    uint32_t streams = 0;   // set by frvm_enqueue: the K the launch uses
 };
 
 // sum_j inst[base + j] * l_{j - rot}(x) for one instance query of every proof (lib.rs:173-218; l_i_range poly/domain.rs:187-212)

@@ -19,7 +19,7 @@ template <class T> int dev_alloc(T*& p, size_t count) {
 int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     const Plan& pl = pd->host;
     size_t N = b->max_proofs, G = b->groups;
-    size_t sig = pl.guard_term_order.size() * 977u + G * 7919u + pl.inst_queries.size() * 31u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + (size_t)pl.n_slots2 * 1009u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
+    size_t sig = pl.guard_term_order.size() * 977u + G * 7919u + pl.inst_queries.size() * 31u + (size_t)pl.opts.transcript * 77u + (size_t)pl.opts.multiopen * 131u + (size_t)pl.n_points * 1000003u + (size_t)pl.n_slots * 10007u + ((size_t)pl.n_slots_k[0] + pl.n_slots_k[1] + pl.n_slots_k[2]) * 1009u + pl.n_shared * 101u + pl.stream.size() + pl.proof_len * 7u + pl.n_instance_values * 13u + pl.n_challenges;
     if (b->cap_plan_sig == sig && b->pts) return 0;
     int rc;
     uint32_t words = (uint32_t)((pl.stream.size() + 7) / 8);
@@ -33,7 +33,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->words, (size_t)words * N))) return rc;
     if ((rc = dev_alloc(b->chal, (size_t)pl.squeeze_at.size() * N))) return rc;
     if ((rc = dev_alloc(b->mult, N))) return rc;
-    if ((rc = dev_alloc(b->slots, (size_t)std::max(pl.n_slots, pl.n_slots2) * N))) return rc;
+    if ((rc = dev_alloc(b->slots, (size_t)std::max(std::max(pl.n_slots, pl.n_slots_k[0]), std::max(pl.n_slots_k[1], pl.n_slots_k[2])) * N))) return rc;
     if ((rc = dev_alloc(b->msm_scal, (N * pl.n_points + G * pl.n_shared) * 8))) return rc;
     if ((rc = dev_alloc(b->shared, (size_t)pl.n_shared * N))) return rc;
     if ((rc = dev_alloc(b->left_scal, N * pl.n_points * 8))) return rc;
@@ -167,8 +167,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
             if ((rc = instance_eval_enqueue(s, ia))) return rc;
         }
     }
-    for (int q = 0; q < 2; ++q) { a.code2[q] = pd->code2[q]; a.n_code2[q] = (uint32_t)pl.code2[q].size(); }
-    a.n_slots2 = pl.n_slots2;
+    for (int k = 0; k < 3; ++k) { for (int q = 0; q < k + 2; ++q) { a.code_k[k][q] = pd->code_k[k][q]; a.n_code_k[k][q] = (uint32_t)pl.code_k[k][q].size(); } a.n_slots_k[k] = pl.n_slots_k[k]; }
     if ((rc = frvm_enqueue(s, a, pl.n_slots))) return rc;
     mark();
     if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, G, b->msm_scal))) return rc; }

@@ -528,19 +528,19 @@ __global__ void __launch_bounds__(64) k_frvm(FrvmArgs a, uint32_t lds_slots) {
     const SlotFile sf{frvm_lds, lds_slots, a.slots, a.n, p, threadIdx.x};
     frvm_run<false>(a, a.code, a.n_code, sf, p, true);
 }
-// Two instruction streams per proof (vkplan.hip: Builder::emit2): the two waves of a workgroup work on the SAME 64 proofs — wave w
-// runs stream w — and share the slot file; values cross between them over OP_BARRIER only.  While one wave sits in the batched
-// inversion's single inverse (a sixth of the program's work, indivisible), the other evaluates the expressions that do not need it.
-__global__ void __launch_bounds__(128) k_frvm2(FrvmArgs a, uint32_t lds_slots) {
+// Several instruction streams per proof (vkplan.hip: Builder::emit_streams): the K waves of a workgroup work on the SAME 64 proofs —
+// wave w runs stream w — and share the slot file; values cross between them over OP_BARRIER only.  While one wave sits in the batched
+// inversion's single inverse (a sixth of the program's work, indivisible), the others evaluate the expressions that do not need it.
+__global__ void __launch_bounds__(64 * FRVM_MAX_STREAMS) k_frvm2(FrvmArgs a, uint32_t lds_slots) {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ uint32_t frvm_lds[];
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, k = a.streams - 2;
     const uint32_t p_raw = blockIdx.x * 64 + lane;
     const bool live = p_raw < a.n;
     const uint32_t p = live ? p_raw : a.n - 1;   // lanes past the end shadow the last proof: they read its inputs, write nothing, and keep the barriers whole
     // (a shadow lane has its own LDS lane but shares the last proof's global slots: it writes there exactly what that proof's lane writes)
     const SlotFile sf{frvm_lds, lds_slots, a.slots, a.n, p, lane};
-    frvm_run<true>(a, w ? a.code2[1] : a.code2[0], w ? a.n_code2[1] : a.n_code2[0], sf, p, live);
+    frvm_run<true>(a, a.code_k[k][w], a.n_code_k[k][w], sf, p, live);
 }
 
 // msm_scal[n*np + g*n_shared + j] = canonical( sum over the proofs p of group g of shared[j][p] )
@@ -626,8 +626,12 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     // half of it up to 384.
     const uint32_t waves = (a.n + 63) / 64;
     const bool one_stream = getenv("H2V_FRVM_ONE_STREAM") != nullptr;   // knob, read per call: tests switch it
-    const bool two = a.code2[0] && a.code2[1] && a.n_code2[0] && a.n_code2[1] && !one_stream;
-    if (two) n_slots = a.n_slots2;
+    // streams per proof: as many as leave every wave of the launch a SIMD of its own (1024 SIMDs)
+    uint32_t K = waves <= 341 ? 4u : 2u;   // measured at 320 workgroups: 260 / 255 / 242 us with 2 / 3 / 4 streams (four still win with 1280 waves)
+    if (const char* e = getenv("H2V_FRVM_STREAMS")) K = (uint32_t)atoi(e);
+    const bool two = !one_stream && K >= 2 && K <= FRVM_MAX_STREAMS && a.code_k[K - 2][0] && a.n_code_k[K - 2][0];
+    FrvmArgs ak = a;
+    if (two) { n_slots = a.n_slots_k[K - 2]; ak.streams = K; }
     // (a launch with more workgroups than that is a throughput launch — several of them are in flight — and an LDS-hungry kernel keeps
     // the other kernels' workgroups off its CUs: a small slice then)
     uint32_t budget = waves <= 256 ? 156 * 1024 : (waves <= 384 ? 78 * 1024 : 36 * 1024);
@@ -640,7 +644,7 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
         H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_frvm2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         granted.store(160 * 1024);
     }
-    if (two) hipLaunchKernelGGL(k_frvm2, dim3(waves), dim3(128), lds, s, a, lds_slots);
+    if (two) hipLaunchKernelGGL(k_frvm2, dim3(waves), dim3(64 * K), lds, s, ak, lds_slots);
     else hipLaunchKernelGGL(k_frvm, dim3(waves), dim3(64), lds, s, a, lds_slots);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;

@@ -64,6 +64,7 @@ enum VmOp : uint32_t {
     OP_BARRIER = 18,       // two-stream programs: both streams of a proof meet here (values cross between them only over a barrier)
 };
 struct VmInstr { uint32_t op, d, a, b; };
+#define FRVM_MAX_STREAMS 4
 #define VM_CONST_OPERAND 0x80000000u   // operand a / b of MUL, ADD, SUB: consts[index] instead of a slot
 
 struct TranscriptSrc {  // one byte of the absorbed stream
@@ -91,8 +92,9 @@ struct Plan {
     std::vector<VmInstr> code;
     std::vector<Fr> consts;
     uint32_t n_slots = 0;
-    std::vector<VmInstr> code2[2];          // the same program as two instruction streams per proof (k_frvm2), with its own slot numbering
-    uint32_t n_slots2 = 0;
+    // the same program as 2, 3 and 4 instruction streams per proof (k_frvm2; index K - 2), each with its own slot numbering
+    std::vector<VmInstr> code_k[3][FRVM_MAX_STREAMS];
+    uint32_t n_slots_k[3] = {0, 0, 0};
     // MSM map
     uint32_t n_shared = 0;                  // fixed (queried) + permutation + g
     std::vector<G1A> shared_bases;
@@ -119,7 +121,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
 struct PlanDevice {
     Plan host;
     VmInstr* code = nullptr;
-    VmInstr* code2[2] = {nullptr, nullptr};
+    VmInstr* code_k[3][FRVM_MAX_STREAMS] = {{nullptr}};
     Fr* consts = nullptr;
     TranscriptSrc* stream = nullptr;
     uint32_t* squeeze_at = nullptr;

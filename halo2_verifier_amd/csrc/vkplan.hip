@@ -308,8 +308,9 @@ struct Builder {
             default: return 0.5;   // loads (from_raw) and stores (to_raw)
         }
     }
-    mutable double makespan2 = 0;   // the scheduler's estimate for emit2's program, in products
-    void emit2(std::vector<VmInstr> code[2], uint32_t& n_slots) const {
+    mutable double makespan_k = 0;   // the scheduler's estimate for emit_streams' last program, in products
+    // K instruction streams (K <= FRVM_MAX_STREAMS): see the comment above; a barrier is executed by ALL streams.
+    void emit_streams(const int K, std::vector<VmInstr>* code, uint32_t& n_slots) const {
         const size_t n = nodes.size();
         static const double BAR = getenv("H2V_FRVM_BAR") ? atof(getenv("H2V_FRVM_BAR")) : 0.3;   // what the scheduler charges for a barrier, in products
         auto n_operands = [&](const Node& nd) -> int {
@@ -321,17 +322,19 @@ struct Builder {
         };
         auto is_compute = [&](Val v) { return nodes[v].op != OP_CONST && !is_load(nodes[v].op); };
         auto inline_const = [&](const Node& consumer, Val v) { return nodes[v].op == OP_CONST && takes_const_operands(consumer.op); };
+        auto operand = [&](Val v, int j) -> Val { return j ? nodes[v].b : nodes[v].a; };
+        auto distinct = [&](Val v, int j) { return !(j == 1 && nodes[v].b == nodes[v].a); };
         // longest path to the end (compute nodes)
         std::vector<double> bl(n, 0.0);
         std::vector<std::vector<Val>> succ(n);
-        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) for (int j = 0; j < n_operands(nodes[i]); ++j) { const Val v = j ? nodes[i].b : nodes[i].a; if (is_compute(v) && !(j == 1 && nodes[i].b == nodes[i].a)) succ[v].push_back((Val)i); }
+        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) for (int j = 0; j < n_operands(nodes[i]); ++j) { const Val v = operand((Val)i, j); if (is_compute(v) && distinct((Val)i, j)) succ[v].push_back((Val)i); }
         for (size_t i = n; i-- > 0;) if (is_compute((Val)i)) { double m = 0; for (Val sc : succ[i]) m = std::max(m, bl[sc]); bl[i] = m + op_weight(nodes[i]); }
         struct Item { int kind; Val v; double fin; };   // 0: compute node, 1: private load / constant, 2: barrier; fin: scheduled finish time
-        std::vector<Item> items[2];
+        std::vector<std::vector<Item>> items(K);
         std::vector<int> stream_of(n, -1);
         std::vector<uint32_t> bar_at(n, 0);      // barriers of its stream that precede the node
         std::vector<size_t> pos(n, 0);           // index of the node's item in its stream
-        std::vector<char> loaded[2] = {std::vector<char>(n, 0), std::vector<char>(n, 0)};
+        std::vector<std::vector<char>> loaded(K, std::vector<char>(n, 0));
         std::vector<int> missing(n, 0);
         std::vector<Val> ready;
         size_t left = 0;
@@ -339,33 +342,43 @@ struct Builder {
         for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) {
             ++left;
             int m = 0;
-            for (int j = 0; j < n_operands(nodes[i]); ++j) { const Val v = j ? nodes[i].b : nodes[i].a; if (is_compute(v) && !(j == 1 && nodes[i].b == nodes[i].a)) ++m; }
+            for (int j = 0; j < n_operands(nodes[i]); ++j) if (is_compute(operand((Val)i, j)) && distinct((Val)i, j)) ++m;
             missing[i] = m;
             if (!m) ready.push_back((Val)i);
         }
-        double clk[2] = {0, 0};
+        std::vector<double> clk(K, 0.0);
+        std::vector<size_t> last_bar(K, 0);      // index of the stream's last barrier item + 1 (0: none): a new barrier goes behind it
         uint32_t bars = 0;
         Val last_node = (Val)-1;
         static const double SLACK = getenv("H2V_FRVM_SLACK") ? atof(getenv("H2V_FRVM_SLACK")) : 1.0;
-        // where stream q could start v: its own clock, or — if an operand sits in the other stream o behind no barrier yet — after a
-        // new barrier, placed in o right behind the last such operand or, if q is ahead of that, behind the first later item of o that
-        // ends after q's clock (so that o does not wait for q), and at the end of q
-        struct Place { bool bar; size_t p; double start; };
+        // Where stream q could start v: at its own clock — or, if an operand sits in another stream behind no barrier yet, after a
+        // NEW barrier.  A barrier is one item in every stream: at the end of q; in a stream that holds such an operand, behind the
+        // last of them; in every other stream anywhere behind its previous barrier — and in both cases not before the first item
+        // that ends after q's clock, so that the stream does not wait for q.  All streams leave it at the latest arrival + BAR.
+        struct Place { bool bar; std::vector<size_t> p; double start; };   // p[r]: the barrier goes behind item p[r] - 1 of stream r (p[r] = insertion index)
         auto place = [&](Val v, int q) -> Place {
-            const int o = q ^ 1;
-            bool need = false; size_t pmax = 0;
+            Place pl{false, {}, clk[q]};
+            std::vector<size_t> lo(K, 0);
             for (int j = 0; j < n_operands(nodes[v]); ++j) {
-                const Val u = j ? nodes[v].b : nodes[v].a;
-                if (is_compute(u) && stream_of[u] == o && bar_at[u] == bars) { pmax = need ? std::max(pmax, pos[u]) : pos[u]; need = true; }
+                const Val u = operand(v, j);
+                if (is_compute(u) && stream_of[u] != q && bar_at[u] == bars) { pl.bar = true; lo[stream_of[u]] = std::max(lo[stream_of[u]], pos[u] + 1); }
             }
-            if (!need) return Place{false, 0, clk[q]};
-            size_t p = pmax;
-            while (p + 1 < items[o].size() && items[o][p].fin < clk[q]) ++p;
-            return Place{true, p, std::max(items[o][p].fin, clk[q]) + BAR};
+            if (!pl.bar) return pl;
+            pl.p.assign(K, 0);
+            double tb = clk[q];
+            for (int r = 0; r < K; ++r) {
+                if (r == q) continue;
+                size_t ins = std::max(lo[r], last_bar[r]);     // insertion index: items [0, ins) stay in front of the barrier
+                while (ins < items[r].size() && (ins == 0 ? 0.0 : items[r][ins - 1].fin) < clk[q]) ++ins;
+                pl.p[r] = ins;
+                tb = std::max(tb, ins == 0 ? 0.0 : items[r][ins - 1].fin);
+            }
+            pl.start = tb + BAR;
+            return pl;
         };
         auto append = [&](int q, Val v) {
             for (int j = 0; j < n_operands(nodes[v]); ++j) {
-                const Val u = j ? nodes[v].b : nodes[v].a;
+                const Val u = operand(v, j);
                 if (is_compute(u) || inline_const(nodes[v], u) || loaded[q][u]) continue;
                 clk[q] += op_weight(nodes[u]); items[q].push_back({1, u, clk[q]}); loaded[q][u] = 1;
             }
@@ -394,21 +407,30 @@ struct Builder {
             const Val v = ready[best];
             last_node = v;
             ready.erase(ready.begin() + (ptrdiff_t)best);
-            const Place pl[2] = {place(v, 0), place(v, 1)};
-            int q = pl[0].start < pl[1].start - 1e-9 ? 0 : (pl[1].start < pl[0].start - 1e-9 ? 1 : (pl[0].bar ? 1 : 0));
-            if (pl[q].bar) {
-                const int o = q ^ 1;
-                const double tb = pl[q].start;                       // both streams leave the barrier at tb
-                const size_t p = pl[q].p;
-                const double shift = tb - items[o][p].fin;            // what the items of o behind the barrier are delayed by
-                items[o].insert(items[o].begin() + (ptrdiff_t)p + 1, Item{2, 0, tb});
-                for (size_t k = p + 2; k < items[o].size(); ++k) {
-                    items[o][k].fin += shift;
-                    if (items[o][k].kind == 0) { pos[items[o][k].v] = k; bar_at[items[o][k].v] = bars + 1; }
+            int q = 0;
+            Place chosen = place(v, 0);
+            for (int r = 1; r < K; ++r) {
+                Place c = place(v, r);
+                if (c.start < chosen.start - 1e-9 || (c.start < chosen.start + 1e-9 && chosen.bar && !c.bar)) { chosen = c; q = r; }
+            }
+            if (chosen.bar) {
+                const double tb = chosen.start;                       // every stream leaves the barrier at tb
+                for (int r = 0; r < K; ++r) {
+                    if (r == q) continue;
+                    const size_t ins = chosen.p[r];
+                    const double before = ins == 0 ? 0.0 : items[r][ins - 1].fin;
+                    const double shift = tb - before;                 // what the items of r behind the barrier are delayed by
+                    items[r].insert(items[r].begin() + (ptrdiff_t)ins, Item{2, 0, tb});
+                    for (size_t k = ins + 1; k < items[r].size(); ++k) {
+                        items[r][k].fin += shift;
+                        if (items[r][k].kind == 0) { pos[items[r][k].v] = k; bar_at[items[r][k].v] = bars + 1; }
+                    }
+                    clk[r] = items[r].back().fin;
+                    last_bar[r] = ins + 1;
                 }
-                clk[o] = items[o].back().fin;
                 items[q].push_back(Item{2, 0, tb});
                 clk[q] = tb;
+                last_bar[q] = items[q].size();
                 ++bars;
             }
             append(q, v);
@@ -417,15 +439,15 @@ struct Builder {
             for (Val sc : succ[v]) if (--missing[sc] == 0) now_ready.push_back(sc);
             for (Val sc : now_ready) { if (is_store(sc)) append(q, sc); else ready.push_back(sc); }
         }
-        makespan2 = std::max(clk[0], clk[1]);
+        makespan_k = *std::max_element(clk.begin(), clk.end());
         // ---- slots.  Value ids: compute node v -> v; private load / constant u of stream q -> n * (1 + q) + u
         auto value_of = [&](Val u, int q) -> size_t { return is_compute(u) ? (size_t)u : n * (size_t)(1 + q) + u; };
-        const size_t NV = 3 * n;
+        const size_t NV = (size_t)(K + 1) * n;
         std::vector<uint32_t> last_epoch(NV, 0), slot(NV, 0);
         std::vector<char> shared(NV, 0), has_def(NV, 0);
         std::vector<int> owner(NV, -1);
         std::vector<size_t> last_pos(NV, 0);   // position of the last use in the owner's stream (private values)
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < K; ++q) {
             uint32_t ep = 0;
             for (size_t k = 0; k < items[q].size(); ++k) {
                 const Item& it = items[q][k];
@@ -440,14 +462,14 @@ struct Builder {
                 if (nd.has_result) { const size_t id = it.kind == 1 ? value_of(it.v, q) : (size_t)it.v; has_def[id] = 1; touch(id); }
             }
         }
-        // a value's owner is the stream of its definition for compute nodes: fix the cases where a use was seen first (other stream, later epoch)
+        // a compute node belongs to the stream that defines it: a use seen first (another stream, a later epoch) makes it shared
         for (size_t i = 0; i < n; ++i) if (is_compute((Val)i) && stream_of[i] >= 0 && owner[i] != stream_of[i]) { owner[i] = stream_of[i]; shared[i] = 1; }
         uint32_t next = 0;
-        std::vector<uint32_t> local_free[2];
+        std::vector<std::vector<uint32_t>> local_free(K);
         std::vector<std::pair<uint32_t, uint32_t>> pool;   // (slot, first epoch it may be reused in)
         std::vector<std::vector<size_t>> release_after(1);  // shared values by last epoch
         for (size_t id = 0; id < NV; ++id) if (has_def[id] && shared[id]) { if (release_after.size() <= last_epoch[id]) release_after.resize(last_epoch[id] + 1); release_after[last_epoch[id]].push_back(id); }
-        size_t cur[2] = {0, 0};
+        std::vector<size_t> cur(K, 0);
         uint32_t ep = 0;
         auto take = [&](int q) -> uint32_t {
             if (!local_free[q].empty()) { auto itf = std::min_element(local_free[q].begin(), local_free[q].end()); const uint32_t sl = *itf; local_free[q].erase(itf); return sl; }
@@ -457,7 +479,7 @@ struct Builder {
             return next++;
         };
         for (;;) {
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < K; ++q) {
                 size_t& k = cur[q];
                 for (; k < items[q].size() && items[q][k].kind != 2; ++k) {
                     const Item& it = items[q][k];
@@ -485,10 +507,11 @@ struct Builder {
                     code[q].push_back(in);
                 }
             }
-            if (cur[0] >= items[0].size() && cur[1] >= items[1].size()) break;
-            // both streams stand at the same barrier
-            code[0].push_back(VmInstr{OP_BARRIER, 0, 0, 0}); code[1].push_back(VmInstr{OP_BARRIER, 0, 0, 0});
-            ++cur[0]; ++cur[1];
+            bool done = true;
+            for (int q = 0; q < K; ++q) if (cur[q] < items[q].size()) done = false;
+            if (done) break;
+            // all streams stand at the same barrier
+            for (int q = 0; q < K; ++q) { code[q].push_back(VmInstr{OP_BARRIER, 0, 0, 0}); ++cur[q]; }
             if (ep < release_after.size()) for (size_t id : release_after[ep]) pool.push_back({slot[id], ep + 1});
             ++ep;
         }
@@ -1034,7 +1057,7 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     for (uint32_t s2 = 0; s2 < np; ++s2) if (left_scalar[s2] != (Val)-1) b.store_left(b.mul(left_scalar[s2], mult), s2);
 
     b.emit(plan.code, plan.n_slots);
-    b.emit2(plan.code2, plan.n_slots2);
+    for (int K = 2; K <= FRVM_MAX_STREAMS; ++K) b.emit_streams(K, plan.code_k[K - 2], plan.n_slots_k[K - 2]);
     if (getenv("H2V_DUMP_PLAN")) {   // diagnostic: size and instruction mix of the compiled Fr program
         std::map<uint32_t, size_t> hist;
         for (const VmInstr& in : plan.code) ++hist[in.op];
@@ -1067,10 +1090,13 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
             work += weight(nd); cp = std::max(cp, depth[i]);
         }
         fprintf(stderr, "[h2v plan] DAG work %.1f products, critical path %.1f (%zu nodes)\n", work, cp, b.nodes.size());
-        for (int q = 0; q < 2; ++q) {
-            double w = 0; size_t bars = 0;
-            for (const VmInstr& in : plan.code2[q]) { if (in.op == OP_BARRIER) { ++bars; continue; } Node nd{in.op, 0, 0, in.b, false}; w += Builder::op_weight(nd); }
-            fprintf(stderr, "[h2v plan] stream %d: %zu instructions, %zu barriers, %.1f products of work; %u slots; estimated makespan %.1f\n", q, plan.code2[q].size(), bars, w, plan.n_slots2, b.makespan2);
+        for (int K = 2; K <= FRVM_MAX_STREAMS; ++K) {
+            std::vector<VmInstr> tmp[FRVM_MAX_STREAMS]; uint32_t ns = 0;
+            b.emit_streams(K, tmp, ns);
+            size_t bars = 0; for (const VmInstr& in : tmp[0]) if (in.op == OP_BARRIER) ++bars;
+            fprintf(stderr, "[h2v plan] %d streams: estimated makespan %.1f, %zu barriers, %u slots; work per stream:", K, b.makespan_k, bars, ns);
+            for (int q = 0; q < K; ++q) { double w = 0; for (const VmInstr& in : tmp[q]) if (in.op != OP_BARRIER) { Node nd{in.op, 0, 0, in.b, false}; w += Builder::op_weight(nd); } fprintf(stderr, " %.0f", w); }
+            fprintf(stderr, "\n");
         }
     }
     plan.consts = b.consts;
@@ -1088,7 +1114,7 @@ template <class T> static int upload_vec(const std::vector<T>& v, T*& d) {
 int PlanDevice::upload() {
     int rc;
     if ((rc = upload_vec(host.code, code))) return rc;
-    for (int q = 0; q < 2; ++q) if ((rc = upload_vec(host.code2[q], code2[q]))) return rc;
+    for (int k = 0; k < 3; ++k) for (int q = 0; q < k + 2; ++q) if ((rc = upload_vec(host.code_k[k][q], code_k[k][q]))) return rc;
     if ((rc = upload_vec(host.consts, consts))) return rc;
     if ((rc = upload_vec(host.stream, stream))) return rc;
     if ((rc = upload_vec(host.squeeze_at, squeeze_at))) return rc;
@@ -1098,7 +1124,7 @@ int PlanDevice::upload() {
     return 0;
 }
 void PlanDevice::release() {
-    hipFree(code); hipFree(code2[0]); hipFree(code2[1]); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases);
+    hipFree(code); for (int k = 0; k < 3; ++k) for (int q = 0; q < FRVM_MAX_STREAMS; ++q) hipFree(code_k[k][q]); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases);
     code = nullptr; consts = nullptr; stream = nullptr; squeeze_at = nullptr; point_offsets = nullptr; scalar_offsets = nullptr; shared_bases = nullptr;
 }
 
