@@ -62,6 +62,7 @@ struct MsmProblem {
 #define MSM_MAX_PROBLEMS 1024     // per launch (a grouped batch: two channels per group; SingleStrategy: one group per proof)
 #define MSM_PROBLEM_CHUNK 48      // descriptors handed to the device per setter launch (kernel-argument space)
 struct MsmProblemChunk { MsmProblem p[MSM_PROBLEM_CHUNK]; };
+static_assert(sizeof(MsmProblemChunk) <= 4000, "a chunk of problem descriptors travels as one kernel argument (4 KB limit)");
 struct MsmProblems { std::vector<MsmProblem> p; };
 
 // A Jacobian point in its own 128-byte line: the MSM's intermediate arrays are written once per lane at scattered
