@@ -769,9 +769,11 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
     if (lo < hi && lo > 0) {
+        // the doublings in front of lo's highest set bit would act on the identity: start there (the wave runs as many rounds as its largest lo needs)
+        const int top = 31 - (int)__clz((int)lo);
         *scaled = G1J::identity();
-        for (int i = (int)p.c - 1; i >= 0; --i) {
-            g1_dbl_to(scaled, scaled);
+        for (int i = top; i >= 0; --i) {
+            if (i < top) g1_dbl_to(scaled, scaled);
             if ((lo >> i) & 1) g1_add_to(scaled, scaled, run);
         }
         g1_add_to(sum, sum, scaled);
