@@ -399,8 +399,10 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
     for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
     if (t == 0) s.prod[36] = Fq2::zero();
     __syncthreads();
+    uint32_t w_next = s.prog[0];
     for (uint32_t pc = 0; pc < n_ops; ++pc) {
-        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.prog[pc]);   // uniform: decoded on the scalar unit
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_next);   // uniform: decoded on the scalar unit
+        w_next = s.prog[pc + 1 < n_ops ? pc + 1 : pc];   // read while this operation runs (k_pairing2: 0.79 -> 0.75 ms for the same change)
         const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
         if (op <= P_MULL) {
             pair_products(op, ra, rb, s.line, s.reg, s.prod, t);
@@ -443,8 +445,10 @@ __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, co
     for (uint32_t k = t; k < n_steps; k += 2 * PAIR_THREADS) s.prog[k] = prog[k];
     if (tl == 0) s.prod[g][36] = Fq2::zero();
     __syncthreads();
+    uint2 w2_next = s.prog[0];
     for (uint32_t pc = 0; pc < n_steps; ++pc) {
-        const uint2 w2 = s.prog[pc];
+        const uint2 w2 = w2_next;
+        w2_next = s.prog[pc + 1 < n_steps ? pc + 1 : pc];   // the next step's words are read while this one runs: no LDS round trip between a barrier and the decode
         const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g ? w2.y : w2.x));   // uniform per wave: decoded on the scalar unit
         const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
         const bool product = op >= P_SQR && op <= P_MULL;
