@@ -456,40 +456,45 @@ struct SlotFile {
 template <bool TWO> __device__ __forceinline__ void frvm_run(const FrvmArgs& a, const VmInstr* __restrict__ code, uint32_t n_code, const SlotFile& sf, uint32_t p, bool live) {
     const uint32_t n = a.n;
     // an operand of MUL / ADD / SUB is a slot or (VM_CONST_OPERAND) a program constant, read with uniform loads
-    auto opnd = [&](uint32_t x) -> Fr { return (x & VM_CONST_OPERAND) ? a.consts[x & ~VM_CONST_OPERAND] : sf.load(x); };
+    // (an operand that is the previous instruction's result is taken from registers, not read back from the slot file: chains —
+    // Horner folds, prefix products — skip a dependent LDS round trip per instruction.  The test is on wave-uniform instruction words.)
+    Fr last = Fr::zero(); uint32_t last_d = 0xffffffffu;
+    auto slot = [&](uint32_t x) -> Fr { return x == last_d ? last : sf.load(x); };
+    auto opnd = [&](uint32_t x) -> Fr { return (x & VM_CONST_OPERAND) ? a.consts[x & ~VM_CONST_OPERAND] : slot(x); };
+    auto put = [&](uint32_t d, const Fr& v) { sf.store(d, v); last = v; last_d = d; };
     VmInstr nx = code[0];
     for (uint32_t pc = 0; pc < n_code; ++pc) {
         const VmInstr in = nx;  // wave-uniform; the next instruction is fetched while this one executes
         nx = code[pc + 1 < n_code ? pc + 1 : pc];
         switch (in.op) {
-            case OP_BARRIER: if (TWO) __syncthreads(); break;
-            case OP_CONST: sf.store(in.d, a.consts[in.a]); break;
-            case OP_MUL: sf.store(in.d, Fr::mul_inl(opnd(in.a), opnd(in.b))); break;
-            case OP_ADD: sf.store(in.d, opnd(in.a) + opnd(in.b)); break;
-            case OP_SUB: sf.store(in.d, opnd(in.a) - opnd(in.b)); break;
-            case OP_NEG: sf.store(in.d, sf.load(in.a).neg()); break;
+            case OP_BARRIER: if (TWO) __syncthreads(); last_d = 0xffffffffu; break;   // (behind a barrier another stream may own the slot `last` mirrored)
+            case OP_CONST: put(in.d, a.consts[in.a]); break;
+            case OP_MUL: put(in.d, Fr::mul_inl(opnd(in.a), opnd(in.b))); break;
+            case OP_ADD: put(in.d, opnd(in.a) + opnd(in.b)); break;
+            case OP_SUB: put(in.d, opnd(in.a) - opnd(in.b)); break;
+            case OP_NEG: put(in.d, slot(in.a).neg()); break;
             case OP_INV: {
-                Fr v = sf.load(in.a);
+                Fr v = slot(in.a);
                 if (live && v.is_zero()) status_set(a.status, p, H2V_DEV_ST_PANIC);
                 // all lanes invert at once: the divsteps of Fp::inv are branch-free, so the wave stays uniform
-                sf.store(in.d, v.inv());
+                put(in.d, v.inv());
                 break;
             }
-            case OP_POW: sf.store(in.d, sf.load(in.a).pow_u32(in.b)); break;
+            case OP_POW: put(in.d, slot(in.a).pow_u32(in.b)); break;
             case OP_SQRN: {
-                Fr v = sf.load(in.a);
+                Fr v = slot(in.a);
                 for (uint32_t i = 0; i < in.b; ++i) v = v.sqr();
-                sf.store(in.d, v);
+                put(in.d, v);
                 break;
             }
-            case OP_LOAD_SCALAR: sf.store(in.d, fr_from_le32(a.proofs + (size_t)p * a.proof_len + a.scalar_offsets[in.a])); break;  // status already set by k_check_scalars
-            case OP_LOAD_INST: sf.store(in.d, fr_from_le32(a.inst + ((size_t)p * a.ninst + in.a) * 32)); break;
-            case OP_LOAD_CHAL: sf.store(in.d, a.chal[(size_t)in.a * n + p]); break;
-            case OP_LOAD_INSTEVAL: sf.store(in.d, a.insteval[(size_t)in.a * n + p]); break;
-            case OP_LOAD_MULT: sf.store(in.d, a.mult[p]); break;
+            case OP_LOAD_SCALAR: put(in.d, fr_from_le32(a.proofs + (size_t)p * a.proof_len + a.scalar_offsets[in.a])); break;  // status already set by k_check_scalars
+            case OP_LOAD_INST: put(in.d, fr_from_le32(a.inst + ((size_t)p * a.ninst + in.a) * 32)); break;
+            case OP_LOAD_CHAL: put(in.d, a.chal[(size_t)in.a * n + p]); break;
+            case OP_LOAD_INSTEVAL: put(in.d, a.insteval[(size_t)in.a * n + p]); break;
+            case OP_LOAD_MULT: put(in.d, a.mult[p]); break;
             case OP_STORE_MSM: {
                 uint32_t raw[8];
-                sf.load(in.a).to_raw(raw);
+                slot(in.a).to_raw(raw);
                 bool bad = a.status[p] != 0;
                 uint32_t* dst = a.msm_scal + ((size_t)p * a.np + in.b) * 8;
                 if (live) for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
@@ -497,20 +502,20 @@ template <bool TWO> __device__ __forceinline__ void frvm_run(const FrvmArgs& a, 
             }
             case OP_STORE_GUARD: {
                 uint32_t raw[8];
-                sf.load(in.a).to_raw(raw);
+                slot(in.a).to_raw(raw);
                 uint32_t* dst = a.guard_scal + ((size_t)p * a.n_guard + in.b) * 8;
                 if (live) for (int i = 0; i < 8; ++i) dst[i] = raw[i];
                 break;
             }
             case OP_STORE_SHARED: {
-                Fr v = sf.load(in.a);
+                Fr v = slot(in.a);
                 if (a.status[p] != 0) v = Fr::zero();
                 if (live) a.shared[(size_t)in.b * n + p] = v;
                 break;
             }
             case OP_STORE_LEFT: {
                 uint32_t raw[8];
-                sf.load(in.a).to_raw(raw);
+                slot(in.a).to_raw(raw);
                 bool bad = a.status[p] != 0;
                 uint32_t* dst = a.left_scal + ((size_t)p * a.np + in.b) * 8;
                 if (live) for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
