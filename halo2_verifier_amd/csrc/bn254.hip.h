@@ -320,6 +320,34 @@ template <class PR> struct Fp {
     H2V_HD Fp neg() const { return zero() - *this; }
     H2V_HD Fp dbl() const { return *this + *this; }
 
+    // ---- Linear forms WITHOUT the correction step ("lazy").  The results are limb-normalised integers that may exceed 2p; they are
+    // only ever handed to products: mul / sqr / dot2 take any limb-normalised operands (their 64-bit columns hold 27 limb products), and
+    // operands below A p and B p give a product below (1 + A B p/R) p with p/R < 0.0060 — e.g. 8p times 8p still comes out below 1.4p.
+    // A field addition or subtraction with its compare-and-select costs ≈ 65 instructions, these 27-45: in the group law below the
+    // linear operations were 40 % of the instructions.  Every caller states the bounds of what it passes.
+    // limb i of k p (k <= 64), normalised
+    H2V_HD static constexpr uint32_t KP29(uint32_t k, int i) {
+        uint64_t c = 0; uint32_t out = 0;
+        for (int j = 0; j <= i; ++j) { const uint64_t t = (uint64_t)k * PR::P29(j) + c; out = j < 8 ? (uint32_t)(t & H2V_LIMB_MASK) : (uint32_t)t; c = t >> 29; }
+        return out;
+    }
+    // k p - sa a - sb b as an integer (must be >= 0; sa, sb in {-2..2}: a negative coefficient adds), signed carries, no reduction
+    template <uint32_t K, int SA, int SB> __host__ __device__ __forceinline__ static Fp lazy_lin(const Fp& a, const Fp& b) {
+        static_assert(K <= 8 && SA >= -2 && SA <= 2 && SB >= -2 && SB <= 2, "limb sums must stay inside 32 bits");
+        Fp r; int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int32_t w = (int32_t)KP29(K, i) - SA * (int32_t)a.v[i] - SB * (int32_t)b.v[i] + c;
+            if (i < 8) { r.v[i] = (uint32_t)w & H2V_LIMB_MASK; c = w >> 29; } else r.v[i] = (uint32_t)w;
+        }
+        return r;
+    }
+    __host__ __device__ __forceinline__ static Fp lazy_sub(const Fp& a, const Fp& b) { return lazy_lin<2, -1, 1>(a, b); }      // a + 2p - b, b <= 2p
+    __host__ __device__ __forceinline__ static Fp lazy_neg(const Fp& b) { Fp z = zero(); return lazy_lin<2, 0, 1>(z, b); }      // 2p - b,     b <= 2p
+    __host__ __device__ __forceinline__ static Fp lazy_neg2(const Fp& b) { Fp z = zero(); return lazy_lin<4, 0, 2>(z, b); }     // 4p - 2b,    b <= 2p
+    __host__ __device__ __forceinline__ static Fp lazy_dbl(const Fp& a) { Fp z = zero(); return lazy_lin<0, -2, 0>(a, z); }     // 2a
+    __host__ __device__ __forceinline__ static Fp lazy_add2(const Fp& a, const Fp& b) { return lazy_lin<0, -1, -2>(a, b); }     // a + 2b
+
     // Montgomery product a*b/R mod p by product scanning: column k collects a_i*b_(k-i) and m_i*p_(k-i) in one 64-bit
     // accumulator (<= 18 terms < 2^58 each, plus a carry < 2^35), m_k is chosen to clear the column's low 29 bits.
     // Any limb-normalised inputs are safe against overflow; representatives < 2p give a result < 1.04p.

@@ -95,36 +95,43 @@ __host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1
 // In-place forms for the hot loops of the MSM kernels.  They return false — leaving the accumulator untouched — in
 // the two degenerate cases (equal or opposite points), which the caller handles on a slow path OUTSIDE its loop: a
 // call inside the loop would take the accumulator's address and force it out of registers into scratch memory.
+// Both use the lazy linear forms of bn254.hip.h and fold every difference of products into one reduction (dot2):
+//   H = U2 - U1, I = (2H)^2, r = 2(S2 - S1),  X3 = r^2 - I (H + 2 U1),  Y3 = I (r U1 - 2 S1 H) - r X3,  Z3 = 2 Z1 Z2 H
+// (add-2007-bl with J = H I and V = U1 I multiplied out).  Bounds, in multiples of p, for coordinates below 2: U, S < 1.03;
+// H < 3.03; 2H, r < 6.1; I < 1.23 (so "I is zero" is the limb string 0 or p, and I = 0 <=> the x coordinates agree);
+// 8p - H - 2 U1 in (0.9, 8); 4p - 2 S1 <= 4; X3 < 1.28; r U1 - 2 S1 H < 1.15; Y3 < 1.09; Z3 < 1.08 — the results are ordinary
+// representatives below 2p again, nothing downstream sees the lazy values.
 __host__ __device__ __forceinline__ bool g1_madd_fast(G1J& acc, const G1A& q) {
     if (q.is_identity()) return true;
     if (acc.is_identity()) { acc.X = q.x; acc.Y = q.y; acc.Z = Fq::one(); return true; }
-    Fq Z1Z1 = H2V_S(acc.Z);
-    Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, acc.Z), Z1Z1);
-    if (acc.X == U2) return false;
-    Fq H = U2 - acc.X, HH = H2V_S(H), I = HH.dbl().dbl(), J = H2V_M(H, I), rr = (S2 - acc.Y).dbl(), V = H2V_M(acc.X, I);
-    Fq ZH = acc.Z + H;
-    Fq X3 = H2V_S(rr) - J - V.dbl();
-    Fq Y3 = H2V_M(rr, V - X3) - H2V_M(acc.Y, J).dbl();
-    acc.Z = H2V_S(ZH) - Z1Z1 - HH;
-    acc.X = X3; acc.Y = Y3;
+    const Fq Z1Z1 = H2V_S(acc.Z);
+    const Fq U2 = H2V_M(q.x, Z1Z1), S2 = H2V_M(H2V_M(q.y, acc.Z), Z1Z1);
+    const Fq H = Fq::lazy_sub(U2, acc.X), H2 = Fq::lazy_dbl(H), I = H2V_S(H2);
+    if (I.is_zero()) return false;
+    const Fq B = Fq::lazy_neg2(acc.Y), rr = Fq::lazy_add2(B, S2);
+    const Fq X3 = Fq::dot2_inl(rr, rr, I, Fq::template lazy_lin<8, 1, 2>(H, acc.X));
+    const Fq W = Fq::dot2_inl(rr, acc.X, H, B);
+    acc.Y = Fq::dot2_inl(I, W, rr, Fq::lazy_neg(X3));
+    acc.Z = H2V_M(acc.Z, H2);
+    acc.X = X3;
     return true;
 }
 __host__ __device__ __forceinline__ bool g1_add_fast(G1J& acc, const G1J& q) {
     if (q.is_identity()) return true;
     if (acc.is_identity()) { acc.X = q.X; acc.Y = q.Y; acc.Z = q.Z; return true; }
-    Fq Z1Z1 = H2V_S(acc.Z), Z2Z2 = H2V_S(q.Z);
-    Fq U1 = H2V_M(acc.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
-    if (U1 == U2) return false;
-    Fq S1 = H2V_M(H2V_M(acc.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, acc.Z), Z1Z1);
-    Fq H = U2 - U1, H2 = H.dbl(), I = H2V_S(H2), J = H2V_M(H, I), rr = (S2 - S1).dbl(), V = H2V_M(U1, I);
-    Fq ZZ = acc.Z + q.Z;
-    Fq X3 = H2V_S(rr) - J - V.dbl();
-    Fq Y3 = H2V_M(rr, V - X3) - H2V_M(S1, J).dbl();
-    acc.Z = H2V_M(H2V_S(ZZ) - Z1Z1 - Z2Z2, H);
-    acc.X = X3; acc.Y = Y3;
+    const Fq Z1Z1 = H2V_S(acc.Z), Z2Z2 = H2V_S(q.Z);
+    const Fq U1 = H2V_M(acc.X, Z2Z2), U2 = H2V_M(q.X, Z1Z1);
+    const Fq H = Fq::lazy_sub(U2, U1), H2 = Fq::lazy_dbl(H), I = H2V_S(H2);
+    if (I.is_zero()) return false;
+    const Fq S1 = H2V_M(H2V_M(acc.Y, q.Z), Z2Z2), S2 = H2V_M(H2V_M(q.Y, acc.Z), Z1Z1);
+    const Fq B = Fq::lazy_neg2(S1), rr = Fq::lazy_add2(B, S2);
+    const Fq X3 = Fq::dot2_inl(rr, rr, I, Fq::template lazy_lin<8, 1, 2>(H, U1));
+    const Fq W = Fq::dot2_inl(rr, U1, H, B);
+    acc.Y = Fq::dot2_inl(I, W, rr, Fq::lazy_neg(X3));
+    acc.Z = H2V_M(H2V_M(acc.Z, q.Z), H2);
+    acc.X = X3;
     return true;
 }
-
 H2V_FN G1J g1_dbl(const G1J& p) { return g1_dbl_inl(p); }
 H2V_FN G1J g1_add(const G1J& p, const G1J& q) { return g1_add_inl(p, q); }
 H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) { return g1_add_affine_inl(p, q); }

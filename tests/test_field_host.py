@@ -134,6 +134,23 @@ def test_g1_group_law_including_degenerate_cases(curve_exe):
         assert g == w, l
 
 
+def test_fast_group_law_keeps_its_representation_contract_over_long_chains(curve_exe):
+    """The in-place additions compute with lazily reduced linear forms (bn254.hip.h: lazy_lin) and promise ordinary representatives
+    below 2p on the way out.  Chains of a few hundred additions that feed each result into the next — the way msm_accumulate and
+    msm_fixup use them — are checked step by step on the host (contract + agreement with the complete routine) and at the end here."""
+    rnd = random.Random(9)
+    h = lambda x: "%064x" % x
+    lines, want = [], []
+    for k in (1, 2, 50, 400):
+        P = _ec_mul(rnd.randrange(1, 1 << 200), (1, 2))
+        s = _ec_mul((k + 1) * (k + 2) // 2 - 1, P)                     # sum of (i + 2) for i < k
+        for op in ("mchain", "achain"):
+            lines.append(f"{op} {k:x} {h(P[0])} {h(P[1])}"); want.append(f"{h(s[0])} {h(s[1])}")
+    r = subprocess.run([curve_exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().split("\n") == want
+
+
 # ---------------------------------------------------------------- the Fq12 tower on the host
 def _tower_to_flat(c):
     """[c0.c0.c0, c0.c0.c1, c0.c1.c0, ...] (Fq6 c0 = coefficients of w^0, w^2, w^4; c1 = w^1, w^3, w^5; u = w^6 - 9)
