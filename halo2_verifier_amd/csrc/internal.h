@@ -99,7 +99,7 @@ struct MsmWorkspace {
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
     uint32_t* glv = nullptr;         // [cap_list / 2] signed window digits of the launch's terms, window-major per problem (LDS sort path)
-    Fq* beta_x = nullptr;            // [cap_terms] beta * x of every base of the launch (LDS sort path): the x of phi(P) = (beta x, y), made once per term instead of once per list entry
+    G1A* phi_pts = nullptr;          // [cap_terms] phi(P) = (beta x, y) of every base of the launch (LDS sort path): made once per term instead of once per list entry
     uint32_t* seg_total = nullptr;   // [problems * windows] entries per list segment
     uint32_t* seg_start = nullptr;   // [problems * windows + 1] logical start of every segment
     size_t cap_buckets = 0, cap_list = 0;

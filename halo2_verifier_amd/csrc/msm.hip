@@ -157,7 +157,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
     H2V_HIP_CHECK(hipMalloc(&glv, (cap_list / 2 + 1) * 4));   // digit table: one word per (term, window)
-    H2V_HIP_CHECK(hipMalloc(&beta_x, ((size_t)cap_terms + 1) * sizeof(Fq)));
+    H2V_HIP_CHECK(hipMalloc(&phi_pts, ((size_t)cap_terms + 1) * sizeof(G1A)));
     H2V_HIP_CHECK(hipMalloc(&seg_total, ((size_t)128 * cap_problems + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&seg_start, ((size_t)128 * cap_problems + 2) * 4));
     for (int i = 0; i < 2; ++i) if (!ev_acc[i]) H2V_HIP_CHECK(hipEventCreate(&ev_acc[i]));
@@ -179,8 +179,8 @@ void MsmWorkspace::release() {
     if (block_sums) hipFree(block_sums);
     if (partial) hipFree(partial);
     if (glv) hipFree(glv);
-    if (beta_x) hipFree(beta_x);
-    beta_x = nullptr;
+    if (phi_pts) hipFree(phi_pts);
+    phi_pts = nullptr;
     if (seg_total) hipFree(seg_total);
     if (seg_start) hipFree(seg_start);
     glv = seg_total = seg_start = nullptr;
@@ -356,7 +356,7 @@ __device__ __forceinline__ Fq msm_beta_times(const Fq& x) {
     const Fq beta = {{0x18ccb791u, 0x175b1c3au, 0x0b83d6e2u, 0x0e8ed071u, 0x1282bee2u, 0x04220e84u, 0x1fe4017fu, 0x15084d4au, 0x00169119u}};
     return Fq::mul_inl(x, beta);
 }
-__global__ void __launch_bounds__(256) msm_glv_prep(const MsmProblem* __restrict__ prs, uint32_t n_problems, MsmPlan p, uint32_t* __restrict__ dig, Fq* __restrict__ beta_x) {
+__global__ void __launch_bounds__(256) msm_glv_prep(const MsmProblem* __restrict__ prs, uint32_t n_problems, MsmPlan p, uint32_t* __restrict__ dig, G1A* __restrict__ phi_pts) {
     const uint32_t q = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_problems) return;
     const MsmProblem pq = prs[q];
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) msm_glv_prep(const MsmProblem* __restrict
         uint32_t any = 0;
         for (int i = 0; i < (int)(sizeof(G1A) / 4); ++i) any |= bw[i];
         nz = any;
-        if (any) beta_x[(size_t)pq.glv_off + t] = msm_beta_times(*reinterpret_cast<const Fq*>(bw));   // x is the point's first coordinate
+        if (any) { const G1A b = *reinterpret_cast<const G1A*>(bw); G1A f; f.x = msm_beta_times(b.x); f.y = b.y; phi_pts[(size_t)pq.glv_off + t] = f; }
     }
     if (!nz) { for (uint32_t w = 0; w < p.windows; ++w) out[(size_t)w * pq.n] = 0; return; }
     GlvHalf h[2];
@@ -476,18 +476,21 @@ __global__ void __launch_bounds__(1024) msm_seg_scan(const uint32_t* __restrict_
 
 // the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y) — split into the load and the fix-up so that
 // the load of the next entry can be issued before the additions of the current one
-// `beta_x` (may be null): the table of beta * x per term that msm_glv_prep leaves on the LDS-sort path — an entry of the second GLV
-// half then LOADS its x from there (one 36-byte gather either way) instead of paying a field product per list entry: with 64 chunks
-// side by side some lane needs it in every iteration, so the whole wave paid it every time (9 % of msm_accumulate's multiply-adds).
-__device__ __forceinline__ G1A msm_entry_load(const MsmProblem& q, uint32_t e, const Fq* __restrict__ beta_x) {
+// `phi_pts` (may be null): the table of phi(P) = (beta x, y) per term that msm_glv_prep leaves on the LDS-sort path — an entry of the
+// second GLV half then LOADS its base from there (one 72-byte gather either way) instead of paying a field product per list entry:
+// with 64 chunks side by side some lane needs it in every iteration, so the whole wave paid it every time (9 % of msm_accumulate's
+// multiply-adds).  The price is L2 footprint: what an XCD gathers from grows from the points of ~2.5 problems (both channels of a
+// group index the same array) to those plus a table per problem, and the fetches from memory double (0.36 -> 0.8 GB per 20-step
+// launch, 1.2 TB/s: not a limit; the kernel is 0.72 -> 0.67 ms).  Variants measured: beta x alone (two gathers per entry: 0.68 ms),
+// one (beta x | y | x) record per term serving both halves (0.695 ms, the same fetches).
+__device__ __forceinline__ G1A msm_entry_load(const MsmProblem& q, uint32_t e, const G1A* __restrict__ phi_pts) {
     const uint32_t t = e & MSM_ENTRY_TERM;
     const G1A* b = t < q.n1 ? q.bases + (size_t)t * q.bstride : q.bases2 + (size_t)(t - q.n1) * q.bstride;
-    const Fq* xs = (beta_x && (e & MSM_ENTRY_HALF)) ? beta_x + ((size_t)q.glv_off + t) : &b->x;
-    G1A r; r.x = *xs; r.y = b->y;
-    return r;
+    if (phi_pts && (e & MSM_ENTRY_HALF)) b = phi_pts + ((size_t)q.glv_off + t);
+    return *b;
 }
-__device__ __forceinline__ G1A msm_entry_apply(G1A b, uint32_t e, bool have_beta) {
-    if (!have_beta && (e & MSM_ENTRY_HALF)) b.x = msm_beta_times(b.x);
+__device__ __forceinline__ G1A msm_entry_apply(G1A b, uint32_t e, bool have_phi) {
+    if (!have_phi && (e & MSM_ENTRY_HALF)) b.x = msm_beta_times(b.x);
     if (e & MSM_ENTRY_NEG) b.y = b.y.neg();
     return b;
 }
@@ -594,7 +597,7 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
 }
 __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, const MsmSeg& g,
-                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const Fq* __restrict__ beta_x, uint32_t E, uint32_t CH, uint32_t lane) {
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const G1A* __restrict__ phi_pts, uint32_t E, uint32_t CH, uint32_t lane) {
     const uint32_t chunk_lo = lane * CH;
     if (chunk_lo >= E) return;
     const uint32_t chunk_hi = min(chunk_lo + CH, E);
@@ -607,7 +610,7 @@ __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restric
     bool first = true, ok = true;
     // software pipeline: the (random-access) load of entry pos + 1 is in flight during the ~2500 instructions of addition pos
     uint32_t e_next = list[(size_t)sg * g.stride + (chunk_lo - seg_lo)];
-    G1A raw_next = msm_entry_load(q, e_next, beta_x);
+    G1A raw_next = msm_entry_load(q, e_next, phi_pts);
     for (uint32_t pos = chunk_lo; pos < chunk_hi && ok;) {
         const uint32_t e = e_next;
         const G1A raw = raw_next;
@@ -629,8 +632,8 @@ __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restric
         // list entry two iterations ahead as well, so that no iteration waits for a dependent pair of loads: no further change — the
         // second wave of the SIMD already covers these stalls)
         const uint32_t pos_n = min(pos, chunk_hi - 1);
-        e_next = list[(size_t)sg * g.stride + (pos_n - seg_lo)]; raw_next = msm_entry_load(q_next, e_next, beta_x);
-        ok = g1_madd_fast(acc, msm_entry_apply(raw, e, beta_x != nullptr));
+        e_next = list[(size_t)sg * g.stride + (pos_n - seg_lo)]; raw_next = msm_entry_load(q_next, e_next, phi_pts);
+        ok = g1_madd_fast(acc, msm_entry_apply(raw, e, phi_pts != nullptr));
         if (flush) {
             if (ok) *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
             acc = G1J::identity(); first = false;
@@ -654,7 +657,7 @@ __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restric
 }
 __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g,
-                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const Fq* __restrict__ beta_x) {
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const G1A* __restrict__ phi_pts) {
     const uint32_t E = counts[nb + 1];
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
     // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
@@ -664,7 +667,7 @@ __global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restric
     // The grid (a multiple of 8) covers the host's bound on the entry count (msm_accumulate_blocks); were there more entries than
     // promised (MsmProblem::nnz), a workgroup takes several blocks of chunks — slower, never wrong.
     for (uint32_t j = blockIdx.x / 8; j < per_xcd; j += gridDim.x / 8)
-        msm_accumulate_chunk(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, g, control, lists, beta_x, E, CH, ((blockIdx.x % 8) * per_xcd + j) * 64 + threadIdx.x);
+        msm_accumulate_chunk(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, g, control, lists, phi_pts, E, CH, ((blockIdx.x % 8) * per_xcd + j) * 64 + threadIdx.x);
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
@@ -998,7 +1001,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
                           (size_t)count * p.windows <= (size_t)128 * ws.cap_problems && !getenv("H2V_MSM_GLOBAL_SORT");
     MsmSeg g;
     if (lds_sort) {
-        hipLaunchKernelGGL(msm_glv_prep, dim3((nmax + 255) / 256, count), dim3(256), 0, s, ws.problems, count, p, ws.glv, ws.beta_x);
+        hipLaunchKernelGGL(msm_glv_prep, dim3((nmax + 255) / 256, count), dim3(256), 0, s, ws.problems, count, p, ws.glv, ws.phi_pts);
         if (sort_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
         hipLaunchKernelGGL(msm_sort_lds, dim3(p.windows, count), dim3(MSM_SORT_THREADS), sort_lds, s, ws.problems, ws.glv, p, stride, ws.counts, ws.offsets, ws.list, ws.seg_total);
         hipLaunchKernelGGL(msm_seg_scan, dim3(1), dim3(1024), 0, s, ws.seg_total, p.windows * count, ws.seg_start, ws.counts + nb);
@@ -1026,9 +1029,9 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     // (the profiling events are attached to the dispatch itself — its own start and stop timestamps — instead of being recorded around it:
     // a recorded event is a barrier packet, ~6 us of idle stream on either side of the kernel)
     if (ws.profile) {
-        hipExtLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.ev_acc[0], ws.ev_acc[1], 0, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, lds_sort ? (const Fq*)ws.beta_x : (const Fq*)nullptr);
+        hipExtLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.ev_acc[0], ws.ev_acc[1], 0, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, lds_sort ? (const G1A*)ws.phi_pts : (const G1A*)nullptr);
         ws.profile_recorded = true;
-    } else hipLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, lds_sort ? (const Fq*)ws.beta_x : (const Fq*)nullptr);
+    } else hipLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, lds_sort ? (const G1A*)ws.phi_pts : (const G1A*)nullptr);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64 + MSM_FIXUP_TEAM_BLOCKS), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {
