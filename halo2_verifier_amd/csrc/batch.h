@@ -62,7 +62,7 @@ struct StageArgs {
     uint32_t n;
     const Plan* plan; const PlanDevice* pd;
     const uint8_t* proofs; const uint8_t* inst;
-    G1A* pts; uint8_t* ycanon; int* status;
+    G1A* pts; G1A* phi; uint8_t* ycanon; int* status;
     unsigned long long* words; uint32_t stream_words;
     Fr* chal;
 };
@@ -91,7 +91,8 @@ struct h2v_batch {
     bool launched = false, with_pairing = false;
     // device buffers (sized for max_proofs with the plan of the first upload; re-allocated if a later plan needs more)
     uint8_t* proofs = nullptr; uint8_t* inst = nullptr; uint8_t* tail = nullptr;
-    h2v::G1A* pts = nullptr; uint8_t* ycanon = nullptr; int* status = nullptr;
+    h2v::G1A* pts = nullptr; h2v::G1A* phi = nullptr;   // the batch's points + the VK-wide bases, and their images under the GLV endomorphism (same shape)
+    uint8_t* ycanon = nullptr; int* status = nullptr;
     unsigned long long* words = nullptr; h2v::Fr* chal = nullptr; h2v::Fr* mult = nullptr; h2v::Fr* slots = nullptr;
     uint32_t* msm_scal = nullptr; h2v::Fr* shared = nullptr; uint32_t* left_scal = nullptr;
     h2v::Fr* insteval = nullptr;  // [query][proof] (wide instance vectors)

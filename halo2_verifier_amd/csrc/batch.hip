@@ -29,6 +29,7 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->proofs, N * pl.proof_len))) return rc;
     if ((rc = dev_alloc(b->inst, N * (size_t)pl.n_instance_values * 32))) return rc;
     if ((rc = dev_alloc(b->pts, N * pl.n_points + pl.n_shared))) return rc;
+    if ((rc = dev_alloc(b->phi, N * pl.n_points + pl.n_shared))) return rc;
     if ((rc = dev_alloc(b->ycanon, N * pl.n_points * 32))) return rc;
     if ((rc = dev_alloc(b->words, (size_t)words * N))) return rc;
     if ((rc = dev_alloc(b->chal, (size_t)pl.squeeze_at.size() * N))) return rc;
@@ -111,6 +112,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
         H2V_HIP_CHECK(hipMemcpyAsync(b->tail, rand_tail, 32 * n_tail, hipMemcpyHostToDevice, s));
         // VK-wide bases sit behind the batch's own points so that one MSM covers both
         H2V_HIP_CHECK(hipMemcpyAsync(b->pts + n * (size_t)pl.n_points, pd->shared_bases, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, s));
+        H2V_HIP_CHECK(hipMemcpyAsync(b->phi + n * (size_t)pl.n_points, pd->shared_phi, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, s));
     }
     H2V_HIP_CHECK(hipStreamSynchronize(s));  // the host buffers are the caller's again
     return 0;
@@ -137,7 +139,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     auto mark = [&]() { if (b->profiling >= 2) hipEventRecord(b->ev[ev], s); ++ev; };   // (an event record is a barrier packet: ~6 us of idle stream each)
     mark();
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this launch (uploads) is visible to the auxiliary stream
-    StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->ycanon, b->status, b->words, b->stream_words, b->chal};
+    StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};
     // stage 1: point decompression + canonicity checks; stage 2: absorbed stream, Blake2b challenges, batch multipliers
     if ((rc = decompress_stage_enqueue(s, g))) return rc;
     mark();
@@ -180,9 +182,11 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         for (uint32_t g = 0; g < G; ++g) {
             const size_t first = (size_t)g * gs * np;
             pr.p.push_back(MsmProblem(b->left_scal + first * 8, b->pts + first, b->acc + 2 * g, 8, 1, gs * np));
+            pr.p.back().phi = b->phi + first;
             pr.p.back().nnz = gs * (uint32_t)pl.left_term_order.size();   // the program writes only these slots, the rest stay zero
             pr.p.push_back(MsmProblem(b->msm_scal + first * 8, b->pts + first, b->acc + 2 * g + 1, 8, 1, gs * np,
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
+            pr.p.back().phi = b->phi + first; pr.p.back().phi2 = b->phi + (size_t)n * np;
         }
         b->ws.profile = b->profiling >= 1; b->ws.profile_recorded = false;
         // A launch leaves the accumulators in pieces (MsmSplit): its own pairing checks take the pieces and the whole points are put
@@ -425,7 +429,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
-    hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->ycanon); hipFree(b->results); hipFree(b->words); hipFree(b->chal);
+    hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->phi); hipFree(b->ycanon); hipFree(b->results); hipFree(b->words); hipFree(b->chal);
     hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc);
     hipFree(b->line_ws);
     if (b->results_host) hipHostFree(b->results_host);

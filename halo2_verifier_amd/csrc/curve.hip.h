@@ -117,6 +117,14 @@ __host__ __device__ __forceinline__ G1J g1_add_affine_inl(const G1J& p, const G1
 }
 
 H2V_FN G1J g1_dbl(const G1J& p) { return g1_dbl_inl(p); }
+// x -> beta x, the x coordinate of the GLV endomorphism phi(x, y) = (beta x, y).  beta = the cube root of unity
+// 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48 in Montgomery form (29-bit limbs, R = 2^261); multiplied inline:
+// through the out-of-line Fp::mul the constant travelled as a stack argument (36 bytes of scratch written and read back per call).
+__host__ __device__ __forceinline__ Fq g1_beta_times(const Fq& x) {
+    const Fq beta = {{0x18ccb791u, 0x175b1c3au, 0x0b83d6e2u, 0x0e8ed071u, 0x1282bee2u, 0x04220e84u, 0x1fe4017fu, 0x15084d4au, 0x00169119u}};
+    return Fq::mul_inl(x, beta);
+}
+__host__ __device__ __forceinline__ G1A g1_phi(const G1A& p) { G1A r; r.x = g1_beta_times(p.x); r.y = p.y; return r; }   // (the identity (0, 0) stays the identity)
 H2V_FN G1J g1_add(const G1J& p, const G1J& q) { return g1_add_inl(p, q); }
 H2V_FN G1J g1_add_affine(const G1J& p, const G1A& q) { return g1_add_affine_inl(p, q); }
 

@@ -50,6 +50,8 @@ struct MsmProblem {
     uint32_t sstride, bstride, n;
     uint32_t n1;
     const uint32_t* scalars2; const G1A* bases2;
+    const G1A* phi = nullptr; const G1A* phi2 = nullptr;   // optional: phi(P) = (beta x, y) of every base, arrays parallel to bases / bases2 (same stride).  Without them
+                                                           // the launch makes its own table (msm_glv_prep); the verifier's points carry theirs from decompression
     uint32_t glv_off = 0;   // first record of this problem in the launch's GLV table (set by msm_enqueue_multi)
     uint32_t sub_first = 0, sub_count = 0;   // set by msm_enqueue_multi when it cuts a large problem into sub-problems (their window sums are merged)
     uint32_t nnz = 0;       // if non-zero: a promise that at most this many of the n scalars are non-zero (sizes msm_accumulate's grid; a broken
@@ -60,7 +62,7 @@ struct MsmProblem {
         : scalars(s), bases(b), out(o), sstride(ss), bstride(bs), n(n1_ + n2), n1(n1_), scalars2(s2), bases2(b2) {}
 };
 #define MSM_MAX_PROBLEMS 1024     // per launch (a grouped batch: two channels per group; SingleStrategy: one group per proof)
-#define MSM_PROBLEM_CHUNK 48      // descriptors handed to the device per setter launch (kernel-argument space)
+#define MSM_PROBLEM_CHUNK 44      // descriptors handed to the device per setter launch (kernel-argument space)
 struct MsmProblemChunk { MsmProblem p[MSM_PROBLEM_CHUNK]; };
 static_assert(sizeof(MsmProblemChunk) <= 4000, "a chunk of problem descriptors travels as one kernel argument (4 KB limit)");
 struct MsmProblems { std::vector<MsmProblem> p; };

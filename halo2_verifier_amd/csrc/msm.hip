@@ -349,13 +349,6 @@ __global__ void __launch_bounds__(MSM_TILE_THREADS) msm_count_or_scatter(const M
 // digit table: for problem q (first word dig_off = glv_off * windows), window w, term t: word [dig_off + w * n + t] holds the two
 // signed digits of the term's GLV halves, 16 bits each: magnitude (0 = no entry) | 0x8000 when the ENTRY is negated (digit sign xor
 // the half's sign).  Written window-major so that the sort of window w reads n consecutive words.
-// Montgomery form (29-bit limbs, R = 2^261) of the cube root of unity 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
-// (multiplied inline: through the out-of-line Fp::mul the constant travelled as a stack argument — 36 bytes of scratch written and
-// read back per entry, which the counters showed as ~0.25 GB of the stage's write traffic)
-__device__ __forceinline__ Fq msm_beta_times(const Fq& x) {
-    const Fq beta = {{0x18ccb791u, 0x175b1c3au, 0x0b83d6e2u, 0x0e8ed071u, 0x1282bee2u, 0x04220e84u, 0x1fe4017fu, 0x15084d4au, 0x00169119u}};
-    return Fq::mul_inl(x, beta);
-}
 __global__ void __launch_bounds__(256) msm_glv_prep(const MsmProblem* __restrict__ prs, uint32_t n_problems, MsmPlan p, uint32_t* __restrict__ dig, G1A* __restrict__ phi_pts) {
     const uint32_t q = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_problems) return;
@@ -370,7 +363,7 @@ __global__ void __launch_bounds__(256) msm_glv_prep(const MsmProblem* __restrict
         uint32_t any = 0;
         for (int i = 0; i < (int)(sizeof(G1A) / 4); ++i) any |= bw[i];
         nz = any;
-        if (any) { const G1A b = *reinterpret_cast<const G1A*>(bw); G1A f; f.x = msm_beta_times(b.x); f.y = b.y; phi_pts[(size_t)pq.glv_off + t] = f; }
+        if (any && !(t < pq.n1 ? pq.phi : pq.phi2)) phi_pts[(size_t)pq.glv_off + t] = g1_phi(*reinterpret_cast<const G1A*>(bw));   // (callers that bring phi(P) with their bases skip this)
     }
     if (!nz) { for (uint32_t w = 0; w < p.windows; ++w) out[(size_t)w * pq.n] = 0; return; }
     GlvHalf h[2];
@@ -479,18 +472,24 @@ __global__ void __launch_bounds__(1024) msm_seg_scan(const uint32_t* __restrict_
 // `phi_pts` (may be null): the table of phi(P) = (beta x, y) per term that msm_glv_prep leaves on the LDS-sort path — an entry of the
 // second GLV half then LOADS its base from there (one 72-byte gather either way) instead of paying a field product per list entry:
 // with 64 chunks side by side some lane needs it in every iteration, so the whole wave paid it every time (9 % of msm_accumulate's
-// multiply-adds).  The price is L2 footprint: what an XCD gathers from grows from the points of ~2.5 problems (both channels of a
-// group index the same array) to those plus a table per problem, and the fetches from memory double (0.36 -> 0.8 GB per 20-step
-// launch, 1.2 TB/s: not a limit; the kernel is 0.72 -> 0.67 ms).  Variants measured: beta x alone (two gathers per entry: 0.68 ms),
-// one (beta x | y | x) record per term serving both halves (0.695 ms, the same fetches).
+// multiply-adds).  A table PER PROBLEM costs L2 footprint: what an XCD gathers from grows from the points of ~2.5 groups (both
+// channels of a group index the same array) to those plus a table per channel, and the fetches from memory double (0.36 -> 0.8 GB
+// per 20-step launch).  So the verifier's launches bring phi(P) with the points themselves (MsmProblem::phi, written by k_decompress
+// and shared by both channels); the table is for callers that bring bases only (h2v_msm_g1).  Variants measured with the table alone:
+// beta x only (two gathers per entry: 0.68 ms), one (beta x | y | x) record per term serving both halves (0.695 ms, the same fetches).
 __device__ __forceinline__ G1A msm_entry_load(const MsmProblem& q, uint32_t e, const G1A* __restrict__ phi_pts) {
     const uint32_t t = e & MSM_ENTRY_TERM;
-    const G1A* b = t < q.n1 ? q.bases + (size_t)t * q.bstride : q.bases2 + (size_t)(t - q.n1) * q.bstride;
-    if (phi_pts && (e & MSM_ENTRY_HALF)) b = phi_pts + ((size_t)q.glv_off + t);
+    const bool first = t < q.n1;
+    const size_t off = (size_t)(first ? t : t - q.n1) * q.bstride;
+    const G1A* b = (first ? q.bases : q.bases2) + off;
+    if (phi_pts && (e & MSM_ENTRY_HALF)) {
+        const G1A* ph = first ? q.phi : q.phi2;   // the caller's own phi(P), parallel to its bases — else the launch's table
+        b = ph ? ph + off : phi_pts + ((size_t)q.glv_off + t);
+    }
     return *b;
 }
 __device__ __forceinline__ G1A msm_entry_apply(G1A b, uint32_t e, bool have_phi) {
-    if (!have_phi && (e & MSM_ENTRY_HALF)) b.x = msm_beta_times(b.x);
+    if (!have_phi && (e & MSM_ENTRY_HALF)) b.x = g1_beta_times(b.x);
     if (e & MSM_ENTRY_NEG) b.y = b.y.neg();
     return b;
 }
@@ -929,10 +928,12 @@ static MsmProblem msm_problem_slice(const MsmProblem& q, uint32_t first, uint32_
     r.out = nullptr; r.n = len; r.nnz = 0; r.sub_first = 0; r.sub_count = 0;
     if (first < q.n1) {
         r.scalars = q.scalars + (size_t)q.sstride * first; r.bases = q.bases + (size_t)q.bstride * first;
+        if (q.phi) r.phi = q.phi + (size_t)q.bstride * first;
         r.n1 = std::min(q.n1 - first, len);
     } else {
         r.scalars = q.scalars2 + (size_t)q.sstride * (first - q.n1); r.bases = q.bases2 + (size_t)q.bstride * (first - q.n1);
-        r.n1 = len; r.scalars2 = nullptr; r.bases2 = nullptr;
+        r.phi = q.phi2 ? q.phi2 + (size_t)q.bstride * (first - q.n1) : nullptr;
+        r.n1 = len; r.scalars2 = nullptr; r.bases2 = nullptr; r.phi2 = nullptr;
     }
     return r;
 }

@@ -22,7 +22,7 @@ namespace h2v {
 // 32 B in (two 16-byte loads: a point sits at a multiple of 32 bytes inside a proof whose length is a multiple of 32), 72 + 32 B
 // out as 8-byte / 16-byte stores.  Round 1 moved every byte on its own: 13x the algorithmic traffic (profiles/r01_pmc_fetch_write.csv).
 __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict__ proofs, uint32_t proof_len, const uint32_t* __restrict__ point_offsets,
-                                                   uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, uint8_t* __restrict__ ycanon,
+                                                   uint32_t np, uint32_t n_main_points, uint32_t n, G1A* __restrict__ pts, G1A* __restrict__ phi, uint8_t* __restrict__ ycanon,
                                                    int* __restrict__ status) {
     const uint32_t t_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = min(t_raw, n * np - 1);   // lanes past the end shadow the last point (all lanes reach the barriers below); their output is not stored
@@ -72,6 +72,15 @@ __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict_
     for (int i = 0; i < 18; ++i) out_lds[lane * 18 + i] = av[i];
     __syncthreads();
     uint32_t* dp = reinterpret_cast<uint32_t*>(pts + t0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { const uint32_t k = i * 64 + lane; if (k < live * 18) dp[k] = out_lds[k]; }
+    __syncthreads();
+    // phi(P) = (beta x, y) beside every point: the MSM's second GLV half gathers it instead of multiplying per list entry (msm.hip: msm_entry_load)
+    a.x = g1_beta_times(a.x);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out_lds[lane * 18 + i] = av[i];     // (y is still there)
+    __syncthreads();
+    dp = reinterpret_cast<uint32_t*>(phi + t0);
 #pragma unroll
     for (int i = 0; i < 18; ++i) { const uint32_t k = i * 64 + lane; if (k < live * 18) dp[k] = out_lds[k]; }
     __syncthreads();
@@ -575,7 +584,7 @@ int decompress_stage_enqueue(hipStream_t s, const StageArgs& g) {
     const Plan& pl = *g.plan;
     H2V_HIP_CHECK(hipMemsetAsync(g.status, 0, sizeof(int) * n, s));
     uint32_t tp = n * pl.n_points;
-    hipLaunchKernelGGL(k_decompress, dim3((tp + 63) / 64), dim3(64), 0, s, g.proofs, pl.proof_len, g.pd->point_offsets, pl.n_points, pl.n_main_points, n, g.pts, g.ycanon, g.status);
+    hipLaunchKernelGGL(k_decompress, dim3((tp + 63) / 64), dim3(64), 0, s, g.proofs, pl.proof_len, g.pd->point_offsets, pl.n_points, pl.n_main_points, n, g.pts, g.phi, g.ycanon, g.status);
     uint32_t ts = n * (pl.n_scalars + pl.n_instance_values);
     if (ts) hipLaunchKernelGGL(k_check_scalars, dim3((ts + 255) / 256), dim3(256), 0, s, g.proofs, pl.proof_len, g.pd->scalar_offsets, pl.n_scalars, g.inst, pl.n_instance_values, n, g.status);
     H2V_HIP_CHECK(hipGetLastError());

@@ -127,7 +127,7 @@ struct PlanDevice {
     uint32_t* squeeze_at = nullptr;
     uint32_t* point_offsets = nullptr;
     uint32_t* scalar_offsets = nullptr;
-    G1A* shared_bases = nullptr;
+    G1A* shared_bases = nullptr; G1A* shared_phi = nullptr;   // the VK-wide bases and their images under phi (MsmProblem::phi2)
     int upload();
     void release();
 };

@@ -1121,11 +1121,14 @@ int PlanDevice::upload() {
     if ((rc = upload_vec(host.point_offsets, point_offsets))) return rc;
     if ((rc = upload_vec(host.scalar_offsets, scalar_offsets))) return rc;
     if ((rc = upload_vec(host.shared_bases, shared_bases))) return rc;
+    std::vector<G1A> phi;
+    for (const G1A& b : host.shared_bases) phi.push_back(g1_phi(b));
+    if ((rc = upload_vec(phi, shared_phi))) return rc;
     return 0;
 }
 void PlanDevice::release() {
-    hipFree(code); for (int k = 0; k < 3; ++k) for (int q = 0; q < FRVM_MAX_STREAMS; ++q) hipFree(code_k[k][q]); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases);
-    code = nullptr; consts = nullptr; stream = nullptr; squeeze_at = nullptr; point_offsets = nullptr; scalar_offsets = nullptr; shared_bases = nullptr;
+    hipFree(code); for (int k = 0; k < 3; ++k) for (int q = 0; q < FRVM_MAX_STREAMS; ++q) hipFree(code_k[k][q]); hipFree(consts); hipFree(stream); hipFree(squeeze_at); hipFree(point_offsets); hipFree(scalar_offsets); hipFree(shared_bases); hipFree(shared_phi);
+    code = nullptr; consts = nullptr; stream = nullptr; squeeze_at = nullptr; point_offsets = nullptr; scalar_offsets = nullptr; shared_bases = nullptr; shared_phi = nullptr;
 }
 
 int ctx_load_vk(h2v_ctx* ctx, const uint8_t* vk, size_t vk_len, int vk_format) {
