@@ -48,6 +48,14 @@ template <class F> static int run() {
         else if (o == "invf") print(x.inv_fermat());          // the fixed-exponent chain, kept as the cross-check of inv()
         else if (o == "invl") print((x + y - y).inv());       // a lazily reduced operand (representative in [p, 2p) half of the time)
         else if (o == "dot2") print(F::dot2_inl(x, y, z, w));
+        else if (o == "lazy") {             // the lazy linear forms: raw limbs out (the test checks the INTEGER identities and the limb bounds), then products of lazy operands
+            const F a = (x + y) - y, b = (z + w) - w;      // representatives in [p, 2p) half of the time
+            const F s1 = F::lazy_sub(a, b), s2 = F::lazy_dbl(s1), s3 = F::template lazy_lin<8, 1, 2>(s1, b), s4 = F::lazy_neg2(b), s5 = F::lazy_add2(s4, a), s6 = F::lazy_neg(b);
+            const F* all[8] = {&a, &b, &s1, &s2, &s3, &s4, &s5, &s6};
+            for (const F* f : all) { for (int i = 0; i < 9; ++i) printf("%x%c", f->v[i], i == 8 ? ' ' : ','); }
+            printf("\n");
+            print(F::mul_inl(s3, s5)); print(s2.sqr_inl()); print(F::dot2_inl(s2, s5, s3, s4));
+        }
         else if (o == "chain") {            // (((x*y - x) + y)^2 - y) * x : lazily reduced intermediates feed every kind of operation
             F t = x * y - x; t = t + y; t = t.sqr() - y; print(t * x);
         } else if (o == "wide") {           // 9x + (2p - y) + 9(2p - z) + w + x + y as ONE integer combination of the limbs, then from_wide

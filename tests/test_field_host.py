@@ -71,6 +71,37 @@ def test_field_operations_match_big_integers(exe, field):
     assert _run(exe, field, lines) == want
 
 
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_lazy_linear_forms_are_exact_integers_and_feed_products(exe, field):
+    """bn254.hip.h lazy_lin: k p - sa a - sb b computed limb-wise with signed carries and NO reduction.  The results are checked as
+    integers (not modulo p) against the representatives they were computed from, their limbs must be normalised, and products /
+    squares / dot2 of operands up to 8p must still reduce to the right residue."""
+    p = P[field]
+    R = 1 << 261
+    Rinv = pow(R, -1, p)
+    rnd = random.Random(21)
+    h = lambda x: "%064x" % x
+    edge = [0, 1, p - 1, p - 2, (p - 1) // 2, 1 << 253]
+    lines = []
+    for _ in range(300):
+        lines.append("lazy " + " ".join(h(rnd.choice(edge) if rnd.random() < 0.3 else rnd.randrange(p)) for _ in range(4)))
+    out = subprocess.run([exe, field], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = out.stdout.strip().split("\n")
+    assert len(rows) == 4 * len(lines)
+    for k in range(len(lines)):
+        limbs = [[int(t, 16) for t in grp.split(",")] for grp in rows[4 * k].split()]
+        assert len(limbs) == 8
+        for l in limbs:
+            assert all(v < (1 << 29) for v in l[:8]) and l[8] < (1 << 29)
+        a, b, s1, s2, s3, s4, s5, s6 = (sum(v << (29 * i) for i, v in enumerate(l)) for l in limbs)
+        assert a < 2 * p and b < 2 * p
+        assert s1 == a + 2 * p - b and s2 == 2 * s1 and s3 == 8 * p - s1 - 2 * b and s4 == 4 * p - 2 * b and s5 == s4 + 2 * a and s6 == 2 * p - b
+        assert int(rows[4 * k + 1], 16) == s3 * s5 * Rinv * Rinv % p
+        assert int(rows[4 * k + 2], 16) == s2 * s2 * Rinv * Rinv % p
+        assert int(rows[4 * k + 3], 16) == (s2 * s5 + s3 * s4) * Rinv * Rinv % p
+
+
 # ---------------------------------------------------------------- G1 group law on the host
 PQ = P["fq"]
 
