@@ -333,7 +333,7 @@ template <class PR> struct Fp {
     }
     // k p - sa a - sb b as an integer (must be >= 0; sa, sb in {-2..2}: a negative coefficient adds), signed carries, no reduction
     template <uint32_t K, int SA, int SB> __host__ __device__ __forceinline__ static Fp lazy_lin(const Fp& a, const Fp& b) {
-        static_assert(K <= 8 && SA >= -2 && SA <= 2 && SB >= -2 && SB <= 2, "limb sums must stay inside 32 bits");
+        static_assert(K <= 16 && SA >= -2 && SA <= 2 && SB >= -2 && SB <= 2, "limb sums must stay inside 32 bits (the limbs of k p are normalised), the value below 2^261");
         Fp r; int32_t c = 0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {

@@ -819,9 +819,9 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
 
 // ---- msm_final: Horner over the windows — c doublings and one addition per window, ~130 dependent group operations, nothing
 // to parallelise ACROSS operations.  Four lanes (a quad) work on one problem and split the inside of a doubling instead:
-//   level 1   lane 0: A = X^2     lane 1: B = Y^2         lane 2: YZ = Y Z
-//   level 2   lane 0: C = B^2     lane 1: (X + B)^2       lane 2: F = (3A)^2
-//   level 3   every lane: E (D - X3)
+//   level 1   lane 0: A = X^2     lane 1: B = Y^2         lane 2: Z3 = (2Y) Z
+//   level 2   lane 0: C = B^2     lane 1: X B             lane 2: (3A)^2
+//   level 3   every lane: X3 (a carry sweep), Y3 = E (D - X3) - 8C (one dot2)
 // three products deep instead of seven, values exchanged by DPP quad broadcasts (no LDS).  X, Y, Z are replicated in the four
 // lanes; the one addition per window is done redundantly by all of them (nothing to exchange).
 template <int S> __device__ __forceinline__ Fq quad_bcast(const Fq& v) {
@@ -837,19 +837,24 @@ __device__ __forceinline__ Fq fq_sel(bool c, const Fq& a, const Fq& b) {
     return r;
 }
 __device__ __forceinline__ void g1_dbl_quad(G1J& p, uint32_t r) {
-    // dbl-2009-l for a = 0.  The identity (Z = 0) stays the identity: Z3 = 2 Y Z.
-    const Fq p1 = Fq::mul_inl(fq_sel(r == 0, p.X, p.Y), fq_sel(r == 0, p.X, fq_sel(r == 1, p.Y, p.Z)));
-    const Fq A = quad_bcast<0>(p1), B = quad_bcast<1>(p1), YZ = quad_bcast<2>(p1);
-    // operands of level 2 by uniform code: lane 0: 0 + B, lane 1: X + B, lane 2: A + A, then lane 2 adds A once more
-    const Fq u = fq_sel(r == 1, p.X, fq_sel(r == 2, A, Fq::zero())) + fq_sel(r == 2, A, B);
-    const Fq w = u + fq_sel(r == 2, A, Fq::zero());
-    const Fq p2 = w.sqr_inl();
-    const Fq C = quad_bcast<0>(p2), S = quad_bcast<1>(p2), F = quad_bcast<2>(p2), E = quad_bcast<2>(w);
-    const Fq D = (S - A - C).dbl();
-    const Fq X3 = F - D.dbl();
-    p.Y = Fq::mul_inl(E, D - X3) - C.dbl().dbl().dbl();
-    p.X = X3;
-    p.Z = YZ.dbl();
+    // g1_dbl_inl's formulas (curve.hip.h: lazy linear forms, D = 4 X B as a product, X3 through one carry sweep, Y3 one dot2), the
+    // products of a level on different lanes.  The identity (Z = 0) stays the identity: Z3 = (2Y) Z.
+    // level 1   lane 0: A = X^2   lane 1: B = Y^2   lanes 2, 3: Z3 = (2Y) Z
+    const Fq Y2 = Fq::lazy_dbl(p.Y);
+    const Fq p1 = Fq::mul_inl(fq_sel(r == 0, p.X, fq_sel(r == 1, p.Y, Y2)), fq_sel(r == 0, p.X, fq_sel(r == 1, p.Y, p.Z)));
+    const Fq A = quad_bcast<0>(p1), B = quad_bcast<1>(p1), Z3 = quad_bcast<2>(p1);
+    // level 2   lane 0: C = B^2   lane 1: X B   lane 2: E^2, E = 3A   (lane 3: E B, unused)
+    const Fq E = Fq::lazy_add2(A, A);
+    const Fq p2 = Fq::mul_inl(fq_sel(r == 0, B, fq_sel(r == 1, p.X, E)), fq_sel(r == 2, E, B));
+    const Fq C = quad_bcast<0>(p2), XB = quad_bcast<1>(p2), F = quad_bcast<2>(p2);
+    // level 3   every lane: X3 = E^2 - 8 X B, Y3 = E (4 X B - X3) - 8 C
+    const Fq D = Fq::lazy_dbl(Fq::lazy_dbl(XB));
+    int64_t acc[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) acc[l] = (int64_t)F.v[l] + (int64_t)Fq::KP29(9, l) - 2 * (int64_t)D.v[l];
+    p.X = Fq::from_wide(acc);
+    p.Y = Fq::dot2_inl(E, Fq::lazy_sub(D, p.X), C, g1_minus_eight());
+    p.Z = Z3;
 }
 // Horner over the points src[0 .. items) (src[i] weighs 2^(dbl * i)) by the quad that lane r belongs to
 __device__ __forceinline__ G1J msm_horner_quad(const G1JSlot* __restrict__ src, uint32_t items, uint32_t dbl, uint32_t r) {

@@ -1,6 +1,6 @@
 // Host-side exerciser of the product's G1 group law (halo2_verifier_amd/csrc/curve.hip.h), including the in-place fast
 // forms that REPORT the degenerate cases instead of handling them.  Lines on stdin:
-//   mchain k x y | achain k x y (k hex) | add x1 y1 x2 y2 | madd x1 y1 x2 y2 | dbl x1 y1 | fast_madd x1 y1 x2 y2 | fast_add x1 y1 x2 y2 | scaled k x1 y1 x2 y2
+//   mchain k x y | achain k x y | dchain k x y (k hex) | add x1 y1 x2 y2 | madd x1 y1 x2 y2 | dbl x1 y1 | fast_madd x1 y1 x2 y2 | fast_add x1 y1 x2 y2 | scaled k x1 y1 x2 y2
 // coordinates as 64 hex digits ("0"*64, "0"*64 = the identity).  `scaled k`: P1 is first mapped to Jacobian coordinates with
 // Z = k (so that equal points meet with different representations), then added to P2.
 // Output: "x y" canonical hex (identity = zeros), fast_* prefix the line with the returned flag.
@@ -63,6 +63,14 @@ int main() {
         if (n < 3) continue;
         std::string o = op;
         Fq v[5];
+        if (o == "dchain") {      // k doublings in a row, each fed by the last: contract after every one
+            unsigned k = 0; if (sscanf(t[0], "%x", &k) != 1) return 2;
+            Fq x, y; if (!parse(t[1], x) || !parse(t[2], y)) return 2;
+            G1J acc = rescale(aff(x, y), Fq::from_u32(9));
+            for (unsigned i = 0; i < k; ++i) { acc = g1_dbl(acc); if (!contract(acc)) { fprintf(stderr, "coordinate out of [0, 2p) after doubling %u\n", i); return 5; } }
+            print(acc);
+            continue;
+        }
         if (o == "mchain" || o == "achain") {
             unsigned k = 0; if (sscanf(t[0], "%x", &k) != 1) return 2;
             Fq x, y; if (!parse(t[1], x) || !parse(t[2], y)) return 2;

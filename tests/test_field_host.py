@@ -177,6 +177,8 @@ def test_fast_group_law_keeps_its_representation_contract_over_long_chains(curve
         s = _ec_mul((k + 1) * (k + 2) // 2 - 1, P)                     # sum of (i + 2) for i < k
         for op in ("mchain", "achain"):
             lines.append(f"{op} {k:x} {h(P[0])} {h(P[1])}"); want.append(f"{h(s[0])} {h(s[1])}")
+        d = _ec_mul(1 << k, P)
+        lines.append(f"dchain {k:x} {h(P[0])} {h(P[1])}"); want.append(f"{h(d[0])} {h(d[1])}")
     r = subprocess.run([curve_exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip().split("\n") == want
