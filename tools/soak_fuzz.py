@@ -21,4 +21,32 @@ for fam, seed in [("wide", 41), ("wide", 42), ("shuffle", 43), ("wide_m2", 45), 
         F.test_random_corruptions_other_circuits(fam, seed)
     except AssertionError as e:
         bad += 1; print("MISMATCH", fam, seed, str(e)[:200])
+# the group arithmetic on its own: random MSM shapes against the oracle — sizes around the sort / cut thresholds, repeated and opposite bases
+# (the additions' degenerate cases), identity bases, zero / tiny / full-width scalars
+import oracle_lib, srs_util
+import halo2_verifier_amd as h2v
+from srs_util import R_MOD, g1_xy
+P_MOD = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+oracle = oracle_lib.load()
+srs = srs_util.load_srs(os.path.join("tests", "golden", "kzg_bn254_8.srs"))
+ctx = h2v.Context(h2v.ParamsKZG(srs.params_raw, h2v.SerdeFormat.RawBytes))
+pts = [g1_xy(p) for p in srs.g]
+neg = lambda b: b[:32] + ((P_MOD - int.from_bytes(b[32:], "little")) % P_MOD).to_bytes(32, "little")
+rnd = random.Random(99)
+for it in range(int(os.environ.get("SOAK_MSM", "60"))):
+    n = rnd.choice([rnd.randrange(1, 64), rnd.randrange(64, 3000), rnd.randrange(3000, 20000)])
+    pool = rnd.choice([1, 2, 5, 50, len(pts)])
+    kind = rnd.choice(["full", "full", "tiny", "few", "mixed"])
+    few = [rnd.randrange(R_MOD) for _ in range(3)]
+    scalars, bases = [], []
+    for i in range(n):
+        k = {"full": rnd.randrange(R_MOD), "tiny": rnd.randrange(300), "few": rnd.choice(few), "mixed": rnd.choice([0, 1, R_MOD - 1, rnd.randrange(R_MOD), rnd.randrange(1 << 64)])}[kind]
+        b = pts[rnd.randrange(pool)]
+        r = rnd.random()
+        if r < 0.1: b = neg(b)
+        elif r < 0.12: b = bytes(64)
+        scalars.append(k); bases.append(b)
+    if ctx.msm_g1(scalars, bases) != oracle_lib.g1_msm(oracle, scalars, bases):
+        bad += 1; print("MSM MISMATCH", it, n, pool, kind)
+ctx.close()
 print("soak done, mismatches:", bad)
