@@ -272,7 +272,7 @@ def rank_main(args):
         uploads = [(proofs_one * g, inst_one * g, b"".join(tails[:g])) for g in sizes] if reupload else None
 
         def retire(i, timed):
-            ok, st, left, right = batches[i].finish_groups()
+            ok, st, left, right = batches[i].finish_groups(raw_statuses=True)   # every proof's status, as the C array's bytes: all zero <=> all OK
             in_flight[i] = False
             if not all(ok) or st.count(0) != len(st):
                 raise SystemExit(f"verification failed inside the benchmark: ok={ok}")

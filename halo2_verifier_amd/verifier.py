@@ -430,16 +430,18 @@ class Batch:
         check(self._lib.h2v_batch_finish(self._h, st, ctypes.byref(ok), left, right))
         return bool(ok.value), memoryview(st).cast('B').cast('i').tolist()[:self.n], left.raw, right.raw
 
-    def finish_groups(self):
-        """-> (group_ok[groups], statuses, left_xy[groups], right_xy[groups])"""
+    def finish_groups(self, raw_statuses=False):
+        """-> (group_ok[groups], statuses, left_xy[groups], right_xy[groups]).
+        `raw_statuses`: the per-proof statuses as the bytes of the C array (n little-endian int32; all zero <=> every proof OK) instead of
+        a list — turning 20 480 statuses into Python ints costs 0.15 ms, 5 % of the launch they come from."""
         g = self.groups
         st = (ctypes.c_int * max(self.n, 1))()
         ok = (ctypes.c_int * g)()
         left, right = ctypes.create_string_buffer(64 * g), ctypes.create_string_buffer(64 * g)
         check(self._lib.h2v_batch_finish_groups(self._h, st, ok, left, right, g))
         lr, rr = left.raw, right.raw
-        return ([bool(v) for v in ok], memoryview(st).cast('B').cast('i').tolist()[:self.n], [lr[64 * i:64 * i + 64] for i in range(g)],
-                [rr[64 * i:64 * i + 64] for i in range(g)])
+        statuses = bytes(memoryview(st).cast('B')[:4 * self.n]) if raw_statuses else memoryview(st).cast('B').cast('i').tolist()[:self.n]
+        return ([bool(v) for v in ok], statuses, [lr[64 * i:64 * i + 64] for i in range(g)], [rr[64 * i:64 * i + 64] for i in range(g)])
 
     PROFILE_KERNEL = 3   # H2V_PROFILE_KERNEL: the dominant kernel's own timestamps only
 

@@ -101,6 +101,9 @@ def test_grouped_launch_and_single_strategy(pool):
             b.upload(flat, 1024, inst, [8], b"".join(r.to_bytes(32, "little") for r in rand))
             b.launch(with_pairing=True)
             results.append(b.finish_groups())
+            raw = b.finish_groups(raw_statuses=True)      # the same call with the statuses as the C array's bytes
+            assert raw[0] == results[-1][0] and raw[2:] == results[-1][2:]
+            assert raw[1] == b"".join(v.to_bytes(4, "little", signed=True) for v in results[-1][1])
             b.close()
             # one check per proof: every proof its own accumulator pair, its own pieces
             assert ctx.verify_each(P[:20], I2[:20]) == [0] * 20

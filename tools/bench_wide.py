@@ -47,11 +47,11 @@ def run(n):
     for st in range(n):
         i = st % a.depth
         if fl[i]:
-            ok, stt, _, _ = bs[i].finish_groups(); assert all(ok) and not any(stt)
+            ok, stt, _, _ = bs[i].finish_groups(raw_statuses=True); assert all(ok) and stt.count(0) == len(stt)
         bs[i].launch(True); fl[i] = True
     for i in range(a.depth):
         if fl[i]:
-            ok, stt, _, _ = bs[i].finish_groups(); assert all(ok) and not any(stt); fl[i] = False
+            ok, stt, _, _ = bs[i].finish_groups(raw_statuses=True); assert all(ok) and stt.count(0) == len(stt); fl[i] = False
 run(a.depth)
 t = time.perf_counter(); run(a.steps); dt = time.perf_counter() - t
 print(f"{a.circuit} VK, {a.multiopen}/{a.transcript}: batch {a.batch} x {G} groups per launch, depth {a.depth}: {a.batch * G * a.steps / dt:.0f} proofs/s, {dt / a.steps / G * 1e3:.3f} ms per {a.batch}-proof batch, proof {plen} B, stages {bs[0].timings_ms()}")
