@@ -747,6 +747,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
     }
 }
 
+#define MSM_WIN_SLOTS 5   // LDS points per lane of msm_window: running sum, weighted sum, scaled (later the tree), 2 run, 3 run
 // The out-of-line group law with explicit destinations: operands are loaded from wherever they live (LDS here), the
 // result is stored where the caller says — no hidden return-value temporaries in scratch memory.
 __device__ __noinline__ void g1_add_to(G1J* dst, const G1J* a, const G1J* b) { const G1J x = *a, y = *b; *dst = g1_add_inl(x, y); }
@@ -755,7 +756,7 @@ __device__ __noinline__ void g1_dbl_to(G1J* dst, const G1J* a) { const G1J x = *
 // A lone wave per window is latency-bound, and the two inlined additions of the running-sum step are ~70 KB of code —
 // more than the instruction cache, so every iteration streamed its code from L2 (measured 2x the time of the arithmetic).
 // Here the group law is the shared out-of-line routine (one 35 KB body, complete formulas) and the three accumulators of a
-// lane live in LDS (dynamic: 3 x T points, + T for the four-wave tree): kept in private memory across the calls they cost
+// lane live in LDS (dynamic: MSM_WIN_SLOTS x T points; the tree reuses the `scaled` slots): kept in private memory across the calls they cost
 // 0.35 GB of scratch write-backs per launch.
 // Empty buckets are recognised by their count: nobody writes an identity into their slots.
 // A workgroup reduces `wpw` windows, T = blockDim.x / wpw lanes each (T a power of two, msm_window_threads).
@@ -766,7 +767,7 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
     const uint32_t T = blockDim.x / wpw, sub = threadIdx.x / T, t = threadIdx.x % T;
     const uint32_t widx = blockIdx.x * wpw + sub;          // (problem, window) = widx / windows, widx % windows
     const bool live = widx < n_windows;
-    G1J* mine = win_lds + (size_t)sub * 3 * T;
+    G1J* mine = win_lds + (size_t)sub * MSM_WIN_SLOTS * T;
     G1J* run = mine + t;
     G1J* sum = mine + T + t;
     G1J* scaled = mine + 2 * T + t;
@@ -781,7 +782,28 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
         g1_add_to(sum, sum, run);
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
-    if (lo < hi && lo > 0) {
+    if ((slice & (slice - 1)) == 0 && T > 1) {
+        // lo = t * slice with slice a power of two (buckets and T are): (t * run) by FIXED two-bit digits of t against the table
+        // {run, 2 run, 3 run}, then log2(slice) doublings.  A wave runs in lockstep: with the bit-serial double-and-add below some lane
+        // of the 64 had a one at every position, so the wave paid a doubling AND an addition per bit of its largest lo (10 of each at
+        // T = 128) whatever the lanes' own bit counts (a non-adjacent form changed nothing, measured); two-bit digits are 5 additions
+        // and 10 doublings for every lane alike.  (Measured without this phase: 0.255 of the kernel's 0.35 ms.)
+        G1J* run2 = mine + 3 * T + t;
+        G1J* run3 = mine + 4 * T + t;
+        if (lo < hi && t > 0) {
+            g1_dbl_to(run2, run);
+            g1_add_to(run3, run2, run);
+            *scaled = G1J::identity();
+            const int nd = (32 - (int)__clz((int)(T - 1)) + 1) / 2;      // two-bit digits of t < T
+            for (int d = nd - 1; d >= 0; --d) {
+                if (d < nd - 1) { g1_dbl_to(scaled, scaled); g1_dbl_to(scaled, scaled); }
+                const uint32_t dig = (t >> (2 * d)) & 3u;
+                if (dig) g1_add_to(scaled, scaled, dig == 1 ? run : (dig == 2 ? run2 : run3));
+            }
+            for (uint32_t w = slice; w > 1; w >>= 1) g1_dbl_to(scaled, scaled);
+            g1_add_to(sum, sum, scaled);
+        }
+    } else if (lo < hi && lo > 0) {
         // the doublings in front of lo's highest set bit would act on the identity: start there (the wave runs as many rounds as its largest lo needs)
         const int top = 31 - (int)__clz((int)lo);
         *scaled = G1J::identity();
@@ -1049,7 +1071,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
         static const char* wpw_env = getenv("H2V_MSM_WIN_WPW");
         if (T == 64 && p.buckets >= 256 && nw > 256 && nw <= 512) { T = 128; wpw = 2; }
         if (wpw_env && T * (uint32_t)atoi(wpw_env) <= MSM_WIN_THREADS) wpw = (uint32_t)atoi(wpw_env);
-        const size_t win_lds = (size_t)3 * T * wpw * sizeof(G1J);   // 20 KB for one wave, 81 KB for four
+        const size_t win_lds = (size_t)MSM_WIN_SLOTS * T * wpw * sizeof(G1J);   // 34 KB for one wave, 135 KB for four
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
         hipLaunchKernelGGL(msm_window, dim3((nw + wpw - 1) / wpw), dim3(T * wpw), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p, nw, wpw);
     }
