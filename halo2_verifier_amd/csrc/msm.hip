@@ -761,13 +761,13 @@ __device__ __noinline__ void g1_dbl_to(G1J* dst, const G1J* a) { const G1J x = *
 // Empty buckets are recognised by their count: nobody writes an identity into their slots.
 // A workgroup reduces `wpw` windows, T = blockDim.x / wpw lanes each (T a power of two, msm_window_threads).
 __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __restrict__ bucket_pts, const uint32_t* __restrict__ counts, G1JSlot* __restrict__ window_sums, MsmPlan p,
-                                                              uint32_t n_windows, uint32_t wpw) {
+                                                              uint32_t n_windows, uint32_t wpw, uint32_t slots) {
     __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     extern __shared__ G1J win_lds[];
     const uint32_t T = blockDim.x / wpw, sub = threadIdx.x / T, t = threadIdx.x % T;
     const uint32_t widx = blockIdx.x * wpw + sub;          // (problem, window) = widx / windows, widx % windows
     const bool live = widx < n_windows;
-    G1J* mine = win_lds + (size_t)sub * MSM_WIN_SLOTS * T;
+    G1J* mine = win_lds + (size_t)sub * slots * T;     // slots = MSM_WIN_SLOTS, or 3 (no digit table) when the launch wants many small workgroups per CU
     G1J* run = mine + t;
     G1J* sum = mine + T + t;
     G1J* scaled = mine + 2 * T + t;
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
         g1_add_to(sum, sum, run);
     }
     // sum = sum_{b in slice} (b - lo + 1) B_b ; the bucket's weight is (b + 1): add lo * (sum of the slice)
-    if ((slice & (slice - 1)) == 0 && T > 1) {
+    if ((slice & (slice - 1)) == 0 && T > 1 && slots >= MSM_WIN_SLOTS) {
         // lo = t * slice with slice a power of two (buckets and T are): (t * run) by FIXED two-bit digits of t against the table
         // {run, 2 run, 3 run}, then log2(slice) doublings.  A wave runs in lockstep: with the bit-serial double-and-add below some lane
         // of the 64 had a one at every position, so the wave paid a doubling AND an addition per bit of its largest lo (10 of each at
@@ -1071,9 +1071,11 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
         static const char* wpw_env = getenv("H2V_MSM_WIN_WPW");
         if (T == 64 && p.buckets >= 256 && nw > 256 && nw <= 512) { T = 128; wpw = 2; }
         if (wpw_env && T * (uint32_t)atoi(wpw_env) <= MSM_WIN_THREADS) wpw = (uint32_t)atoi(wpw_env);
-        const size_t win_lds = (size_t)MSM_WIN_SLOTS * T * wpw * sizeof(G1J);   // 34 KB for one wave, 135 KB for four
+        // (one-wave workgroups beyond four per CU — launches of more than ~40 groups — keep the 20 KB form without the digit table: 34 KB each would not fit side by side)
+        const uint32_t slots = (T * wpw <= 64 && nw > 1024) ? 3u : (uint32_t)MSM_WIN_SLOTS;
+        const size_t win_lds = (size_t)slots * T * wpw * sizeof(G1J);   // 34 KB for one wave, 135 KB for four
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
-        hipLaunchKernelGGL(msm_window, dim3((nw + wpw - 1) / wpw), dim3(T * wpw), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p, nw, wpw);
+        hipLaunchKernelGGL(msm_window, dim3((nw + wpw - 1) / wpw), dim3(T * wpw), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p, nw, wpw, slots);
     }
     const G1JSlot* sums = ws.window_sums;
     if (cut) {
