@@ -23,6 +23,8 @@ c_vp = ctypes.c_void_p
 c_szp = ctypes.POINTER(ctypes.c_size_t)
 c_intp = ctypes.POINTER(ctypes.c_int)
 
+ABI_VERSION = 3   # include/h2v.h H2V_ABI_VERSION: the struct layouts this binding mirrors
+
 # every symbol include/h2v.h declares: (restype, argtypes)
 SIGNATURES = {
     "h2v_device_count": (c_int, []),
@@ -30,6 +32,8 @@ SIGNATURES = {
     "h2v_ctx_create": (c_int, [c_u8p, c_sz, c_int, c_u8p, c_sz, c_int, c_int, ctypes.POINTER(c_vp)]),
     "h2v_ctx_create_ex": (c_int, [c_u8p, c_sz, c_int, c_u8p, c_sz, c_int, c_int, ctypes.c_void_p, ctypes.POINTER(c_vp)]),
     "h2v_ctx_destroy": (None, [c_vp]),
+    "h2v_abi_version": (c_int, []),
+    "h2v_ctx_set_tuning": (c_int, [c_vp, ctypes.c_void_p]),
     "h2v_ctx_proof_shape": (c_int, [c_vp, c_szp, c_szp, c_szp, c_szp, c_szp]),
     "h2v_msm_g1": (c_int, [c_vp, c_u8p, c_u8p, c_sz, c_u8p, c_intp]),
     "h2v_pairing_check": (c_int, [c_vp, c_u8p, c_u8p, c_intp]),
@@ -76,6 +80,8 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if lib.h2v_abi_version() != ABI_VERSION:
+        raise H2VError(-16, f"{path} has ABI version {lib.h2v_abi_version()}, this binding was written for {ABI_VERSION}: rebuild the library")
     _LIB = lib
     return lib
 

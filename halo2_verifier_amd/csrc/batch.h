@@ -16,6 +16,9 @@ namespace h2v {
 #define H2V_DEV_ST_PANIC (-20)
 #define H2V_DEV_ST_OPENING (-10)
 __device__ __forceinline__ void status_set(int* status, uint32_t p, int dev_code) { atomicMin(&status[p], dev_code); }
+// a status word that another wave of the same kernel may have set (the Fr program's inversion, ordered before this read by a
+// workgroup barrier): read at device scope, past the CU's vector cache, like the atomic that wrote it
+__device__ __forceinline__ int status_get(const int* status, uint32_t p) { return __hip_atomic_load(&status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 inline int status_decode(int dev) {
     switch (dev) {
         case 0: return 0;
@@ -44,6 +47,7 @@ struct FrvmArgs {
     // the same program as 2 / 3 / 4 instruction streams per proof (k_frvm2; index K - 2, slot numbering of its own): frvm_enqueue chooses
     const VmInstr* code_k[3][FRVM_MAX_STREAMS] = {{nullptr}}; uint32_t n_code_k[3][FRVM_MAX_STREAMS] = {{0}}; uint32_t n_slots_k[3] = {0, 0, 0};
     uint32_t streams = 0;   // set by frvm_enqueue: the K the launch uses
+    int force_streams = 0, force_lds_kb = 0;   // h2v_tuning (0 = automatic)
 };
 
 // sum_j inst[base + j] * l_{j - rot}(x) for one instance query of every proof (lib.rs:173-218; l_i_range poly/domain.rs:187-212)

@@ -169,6 +169,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
             if ((rc = instance_eval_enqueue(s, ia))) return rc;
         }
     }
+    a.force_streams = ctx->tuning.frvm_streams; a.force_lds_kb = ctx->tuning.frvm_lds_kb;
     for (int k = 0; k < 3; ++k) { for (int q = 0; q < k + 2; ++q) { a.code_k[k][q] = pd->code_k[k][q]; a.n_code_k[k][q] = (uint32_t)pl.code_k[k][q].size(); } a.n_slots_k[k] = pl.n_slots_k[k]; }
     if ((rc = frvm_enqueue(s, a, pl.n_slots))) return rc;
     mark();
@@ -193,8 +194,8 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         // together beside them (close_enqueue); a launch without a pairing (a shard) exports the pieces, the folded pairing takes them,
         // and the whole points are only made if somebody reads them (ensure_whole).  Worth it while the launch is a latency chain, i.e. few groups.
         b->split = MsmSplit();
-        const char* parts_env = getenv("H2V_MSM_PARTS");   // tuning / test knob, read per launch
-        const uint32_t parts_knob = parts_env ? (uint32_t)atoi(parts_env) : MSM_MAX_PARTS;
+        const uint32_t parts_knob = ctx->tuning.msm_parts > 0 ? (uint32_t)ctx->tuning.msm_parts : MSM_MAX_PARTS;   // h2v_tuning.msm_parts
+        b->ws.tune = ctx->tuning;
         if (n && G <= H2V_SPLIT_MAX_GROUPS && parts_knob > 1) {
             if (b->line_ws_groups < G) {
                 if (b->line_ws) { hipStreamSynchronize(s); hipFree(b->line_ws); b->line_ws = nullptr; b->line_ws_groups = 0; }
@@ -228,7 +229,7 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split))) return rc;   // acc <- the whole points
     if ((rc = point_to_bytes_enqueue(b->aux, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
     H2V_HIP_CHECK(hipEventRecord(b->ev_join, b->aux));
-    if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.ready, G, b->split.parts, b->split.shift, b->line_ws, b->ok))) return rc; }
+    if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.ready, G, b->split.parts, b->split.shift, b->line_ws, b->ok, b->ctx->tuning.pairing_one_stream != 0))) return rc; }
     else if ((rc = pairing_check_enqueue(s, b->ctx->pairing, b->acc, G, b->ok))) return rc;
     H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join, 0));
     return 0;

@@ -25,6 +25,8 @@ struct h2v_ctx {
     std::mutex mu;                 // serialises the single-shot entry points
     h2v::VkDevice* vk = nullptr;   // per-VK compiled program and constants (vkplan.hip)
     int multiopen = 0, transcript = 0, circuit_instances = 1;  // h2v_options
+    int instance_kernel_threshold = 0;                         // h2v_options (debug): 0 = default
+    h2v::Tuning tuning;                                        // h2v_ctx_set_tuning (debug / test): forced kernel variants
     struct h2v_batch* scratch_batch = nullptr;  // kept between one-shot calls (h2v_verify_batch / _each): ~20 device allocations saved per call
 };
 

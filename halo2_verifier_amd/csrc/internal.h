@@ -32,6 +32,14 @@ template <class T> struct DevBuf {
     }
 };
 
+// Forced kernel variants (include/h2v.h: h2v_tuning; every field 0 = automatic).  Lives in the context; a launch copies it into
+// the objects that choose (MsmWorkspace::tune, FrvmArgs, the pairing launcher's argument).  The library reads no environment variable.
+struct Tuning {
+    int frvm_streams = 0, frvm_lds_kb = 0;
+    int msm_parts = 0, msm_global_sort = 0, msm_no_term_split = 0, msm_window_threads = 0, msm_window_wpw = 0, msm_window_slots = 0, msm_affine = 0;
+    int pairing_one_stream = 0;
+};
+
 // ------------------------------------------------------------------ MSM (msm.hip)
 // Pippenger over pooled (scalar, base) terms.  Scalars: canonical little-endian 32-bit words, 8 per
 // term; bases: affine Montgomery, (0,0) = identity (skipped).
@@ -106,6 +114,7 @@ struct MsmWorkspace {
     uint32_t* seg_start = nullptr;   // [problems * windows + 1] logical start of every segment
     size_t cap_buckets = 0, cap_list = 0;
     // optional HIP events around msm_accumulate (the dominant kernel: bench.py's roofline.kernels), recorded when `profile` is set
+    Tuning tune;                     // forced variants for the next launch (copied from the context by the caller)
     bool profile = false, profile_recorded = false;
     hipEvent_t ev_acc[2] = {nullptr, nullptr};
     // max_terms_per_problem sizes the bucket arrays (the window plan follows the largest problem of a launch)

@@ -83,9 +83,9 @@ static inline uint32_t msm_accumulate_blocks(size_t max_entries) {
 // adding the halves) also loses, 0.59 ms; so does a compact group law with out-of-line field products (0.65 ms) — the per-operation
 // cost of this kernel rises with the number of its waves per CU, whatever their grouping.  Hence: four waves per window up to
 // 256 workgroups, one wave beyond.
-static inline uint32_t msm_window_threads(uint32_t buckets, uint32_t n_workgroups = 0xffffffffu) {
+static inline uint32_t msm_window_threads(uint32_t buckets, uint32_t n_workgroups = 0xffffffffu, int forced = 0) {
     if (buckets <= 64) return std::max(1u, buckets);
-    if (n_workgroups != 0xffffffffu) { static const char* e = getenv("H2V_MSM_WIN_T"); if (e) return (uint32_t)atoi(e); }   // tuning knob
+    if (n_workgroups != 0xffffffffu && (forced == 64 || forced == 128 || forced == 256)) return (uint32_t)forced;   // h2v_tuning.msm_window_threads
     if (buckets > 2048 || (buckets >= 256 && n_workgroups <= 256)) return 256u;
     return 64u;
 }
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
             *scaled = other;
             g1_add_to(sum, sum, scaled);
         }
-        if (t == 0) window_sums[widx] = *sum;
+        if (t == 0 && live) window_sums[widx] = *sum;
         return;
     }
     red[t] = *sum;
@@ -988,7 +988,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     // of a problem's sub-problems are added up (msm_merge_windows) before the Horner.
     std::vector<MsmProblem> launch_p, parents_p;
     bool cut = false;
-    if (nmax > MSM_LDS_SORT_MAX_TERMS && !getenv("H2V_MSM_NO_TERM_SPLIT")) {
+    if (nmax > MSM_LDS_SORT_MAX_TERMS && !ws.tune.msm_no_term_split) {
         size_t subs = 0;
         for (uint32_t q = 0; q < n_callers; ++q) subs += msm_subproblems(pr.p[q].n);
         cut = subs <= ws.cap_problems && subs <= MSM_MAX_PROBLEMS && n_callers <= ws.cap_parents;
@@ -1026,7 +1026,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     const uint32_t stride = 2 * nmax;
     const size_t sort_lds = ((size_t)p.buckets + MSM_SORT_THREADS) * 4 + (size_t)stride * 2;
     const bool lds_sort = nmax <= MSM_LDS_SORT_MAX_TERMS && sort_lds <= 150 * 1024 && (size_t)count * p.windows * stride <= ws.cap_list &&
-                          (size_t)count * p.windows <= (size_t)128 * ws.cap_problems && !getenv("H2V_MSM_GLOBAL_SORT");
+                          (size_t)count * p.windows <= (size_t)128 * ws.cap_problems && !ws.tune.msm_global_sort;
     MsmSeg g;
     if (lds_sort) {
         hipLaunchKernelGGL(msm_glv_prep, dim3((nmax + 255) / 256, count), dim3(256), 0, s, ws.problems, count, p, ws.glv, ws.phi_pts);
@@ -1067,12 +1067,12 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
         // window does in 0.48), so beyond 256 windows a workgroup is FOUR waves reducing two windows, two waves each: every wave
         // has a SIMD of its own as long as the launch has at most one workgroup per CU.
         const uint32_t nw = p.windows * count;
-        uint32_t T = msm_window_threads(p.buckets, nw), wpw = 1;
-        static const char* wpw_env = getenv("H2V_MSM_WIN_WPW");
-        if (T == 64 && p.buckets >= 256 && nw > 256 && nw <= 512) { T = 128; wpw = 2; }
-        if (wpw_env && T * (uint32_t)atoi(wpw_env) <= MSM_WIN_THREADS) wpw = (uint32_t)atoi(wpw_env);
+        uint32_t T = msm_window_threads(p.buckets, nw, ws.tune.msm_window_threads), wpw = 1;
+        if (T == 64 && p.buckets >= 256 && nw > 256 && nw <= 512 && !ws.tune.msm_window_threads) { T = 128; wpw = 2; }
+        const uint32_t wpw_forced = (uint32_t)ws.tune.msm_window_wpw;   // h2v_tuning.msm_window_wpw
+        if ((wpw_forced == 1 || wpw_forced == 2 || wpw_forced == 4) && T * wpw_forced <= MSM_WIN_THREADS) wpw = wpw_forced;
         // (one-wave workgroups beyond four per CU — launches of more than ~40 groups — keep the 20 KB form without the digit table: 34 KB each would not fit side by side)
-        const uint32_t slots = (T * wpw <= 64 && nw > 1024) ? 3u : (uint32_t)MSM_WIN_SLOTS;
+        const uint32_t slots = ((T * wpw <= 64 && nw > 1024) || ws.tune.msm_window_slots == 3) ? 3u : (uint32_t)MSM_WIN_SLOTS;
         const size_t win_lds = (size_t)slots * T * wpw * sizeof(G1J);   // 34 KB for one wave, 135 KB for four
         if (win_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
         hipLaunchKernelGGL(msm_window, dim3((nw + wpw - 1) / wpw), dim3(T * wpw), win_lds, s, ws.bucket_pts, ws.counts, ws.window_sums, p, nw, wpw, slots);

@@ -569,7 +569,7 @@ int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_p
     return 0;
 }
 
-int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_ready, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok) {
+int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_ready, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok, bool one_stream) {
     if (!n) return 0;
     if (!pd.prog_merged || pd.n_ops_merged > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
     if (!parts || parts > PL_MAX_PARTS || !d_line_ws) { set_last_error("pairing: bad split"); return H2V_ERR_BAD_ARGUMENT; }
@@ -586,7 +586,7 @@ int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot*
     }
     for (int i = 64; i < PAIR_ITERS; ++i) { its.first[i] = (uint8_t)line++; its.cnt[i] = 1; }
     hipLaunchKernelGGL(k_pair_lines, dim3(PAIR_ITERS, n), dim3(PL_THREADS), 0, s, d_ready, parts, tab, its, lines);
-    const bool one_stream = getenv("H2V_PAIRING_ONE_STREAM") != nullptr;   // knob (read per call: tests switch it): the single-stream table over the same lines
+    // (one_stream: h2v_tuning.pairing_one_stream — the single-stream table over the same lines)
     if (pd.prog2 && !one_stream) hipLaunchKernelGGL(k_pairing2, dim3(n), dim3(2 * PAIR_THREADS), 0, s, n, pd.consts, reinterpret_cast<const uint2*>(pd.prog2), pd.n_steps2, (const Fq2*)lines, d_ok);
     else hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog_merged, pd.n_ops_merged, (const Fq2*)lines, d_ok);
     H2V_HIP_CHECK(hipGetLastError());

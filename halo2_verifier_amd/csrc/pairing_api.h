@@ -45,6 +45,6 @@ struct PairingDevice {
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok);
 // check g over split accumulators: left = sum_j 2^(shift j) piece[(2 g) parts + j], right likewise at 2 g + 1 (MsmSplit), the
 // pieces given line-ready as (X Z, Y, Z^3); d_line_ws: n * H2V_PAIRING_LINE_WS_BYTES of device scratch owned by the caller
-int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_ready, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok);
+int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot* d_ready, uint32_t n, uint32_t parts, uint32_t shift, void* d_line_ws, uint32_t* d_ok, bool one_stream = false);
 
 }  // namespace h2v

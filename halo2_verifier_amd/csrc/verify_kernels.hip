@@ -504,7 +504,7 @@ template <bool TWO> __device__ __forceinline__ void frvm_run(const FrvmArgs& a, 
             case OP_STORE_MSM: {
                 uint32_t raw[8];
                 slot(in.a).to_raw(raw);
-                bool bad = a.status[p] != 0;
+                bool bad = status_get(a.status, p) != 0;
                 uint32_t* dst = a.msm_scal + ((size_t)p * a.np + in.b) * 8;
                 if (live) for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
@@ -518,14 +518,14 @@ template <bool TWO> __device__ __forceinline__ void frvm_run(const FrvmArgs& a, 
             }
             case OP_STORE_SHARED: {
                 Fr v = slot(in.a);
-                if (a.status[p] != 0) v = Fr::zero();
+                if (status_get(a.status, p) != 0) v = Fr::zero();
                 if (live) a.shared[(size_t)in.b * n + p] = v;
                 break;
             }
             case OP_STORE_LEFT: {
                 uint32_t raw[8];
                 slot(in.a).to_raw(raw);
-                bool bad = a.status[p] != 0;
+                bool bad = status_get(a.status, p) != 0;
                 uint32_t* dst = a.left_scal + ((size_t)p * a.np + in.b) * 8;
                 if (live) for (int i = 0; i < 8; ++i) dst[i] = bad ? 0u : raw[i];
                 break;
@@ -639,17 +639,16 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots) {
     // latency chain), so the budget follows the number of workgroups: the whole 160 KB of a CU while there are at most 256,
     // half of it up to 384.
     const uint32_t waves = (a.n + 63) / 64;
-    const bool one_stream = getenv("H2V_FRVM_ONE_STREAM") != nullptr;   // knob, read per call: tests switch it
     // streams per proof: as many as leave every wave of the launch a SIMD of its own (1024 SIMDs)
     uint32_t K = waves <= 341 ? 4u : 2u;   // measured at 320 workgroups: 260 / 255 / 242 us with 2 / 3 / 4 streams (four still win with 1280 waves)
-    if (const char* e = getenv("H2V_FRVM_STREAMS")) K = (uint32_t)atoi(e);
-    const bool two = !one_stream && K >= 2 && K <= FRVM_MAX_STREAMS && a.code_k[K - 2][0] && a.n_code_k[K - 2][0];
+    if (a.force_streams > 0) K = (uint32_t)a.force_streams;   // h2v_tuning.frvm_streams (1 = the single-stream interpreter k_frvm)
+    const bool two = K >= 2 && K <= FRVM_MAX_STREAMS && a.code_k[K - 2][0] && a.n_code_k[K - 2][0];
     FrvmArgs ak = a;
     if (two) { n_slots = a.n_slots_k[K - 2]; ak.streams = K; }
     // (a launch with more workgroups than that is a throughput launch — several of them are in flight — and an LDS-hungry kernel keeps
     // the other kernels' workgroups off its CUs: a small slice then)
     uint32_t budget = waves <= 256 ? 156 * 1024 : (waves <= 384 ? 78 * 1024 : 36 * 1024);
-    if (const char* e = getenv("H2V_FRVM_LDS_KB")) budget = (uint32_t)atoi(e) * 1024;   // tuning knob
+    if (a.force_lds_kb > 0) budget = (uint32_t)std::min(a.force_lds_kb, 156) * 1024;   // h2v_tuning.frvm_lds_kb
     const uint32_t lds_slots = std::min<uint32_t>(n_slots, budget / (H2V_LIMBS * 64 * 4));
     const size_t lds = (size_t)lds_slots * H2V_LIMBS * 64 * 4;
     static std::atomic<size_t> granted{0};   // raising the limit is per function and sticky; do it once per size class

@@ -72,10 +72,11 @@ struct TranscriptSrc {  // one byte of the absorbed stream
     uint8_t kind; uint8_t value; uint32_t offset;
 };
 
-struct PlanOptions { int multiopen = 0; int transcript = 0; int circuit_instances = 1; bool guard_terms = false; };  // h2v_options (+ the h2v_guard_msm variant)
+struct PlanOptions { int multiopen = 0; int transcript = 0; int circuit_instances = 1; bool guard_terms = false; int instance_kernel_threshold = 0; };  // h2v_options (+ the h2v_guard_msm variant)
 
 struct Plan {
     PlanOptions opts;
+    double dag_work = 0, dag_critical_path = 0, makespan_k[3] = {0, 0, 0};   // diagnostics: Fr-program DAG in products; the scheduler's estimate for 2 / 3 / 4 streams
     // proof layout
     uint32_t n_points = 0, n_scalars = 0, proof_len = 0;
     std::vector<uint32_t> point_offsets, scalar_offsets;  // byte offsets into the proof

@@ -312,7 +312,7 @@ struct Builder {
     // K instruction streams (K <= FRVM_MAX_STREAMS): see the comment above; a barrier is executed by ALL streams.
     void emit_streams(const int K, std::vector<VmInstr>* code, uint32_t& n_slots) const {
         const size_t n = nodes.size();
-        static const double BAR = getenv("H2V_FRVM_BAR") ? atof(getenv("H2V_FRVM_BAR")) : 0.3;   // what the scheduler charges for a barrier, in products
+        const double BAR = 0.3;   // what the scheduler charges for a barrier, in products (swept in round 2: 0.1 .. 2.0, flat around 0.3)
         auto n_operands = [&](const Node& nd) -> int {
             switch (nd.op) {
                 case OP_MUL: case OP_ADD: case OP_SUB: return 2;
@@ -324,10 +324,25 @@ struct Builder {
         auto inline_const = [&](const Node& consumer, Val v) { return nodes[v].op == OP_CONST && takes_const_operands(consumer.op); };
         auto operand = [&](Val v, int j) -> Val { return j ? nodes[v].b : nodes[v].a; };
         auto distinct = [&](Val v, int j) { return !(j == 1 && nodes[v].b == nodes[v].a); };
+        // The per-proof status is a value too: OP_INV sets it (a zero where the reference panics) and the stores of the two MSM channels
+        // and of the shared scalars read it (a failed proof's scalars are zeroed).  The scheduler orders VALUE dependencies only, so
+        // with several streams a store could run before the inversion of another stream — whether a panicking proof was zeroed out of
+        // its accumulators depended on wave timing (round-2 review).  Every status-reading store therefore also depends on every
+        // OP_INV ("effect dependency": ordering only — no slot is read, no load is emitted for it).
+        auto reads_status = [&](Val v) { const uint32_t op = nodes[v].op; return op == OP_STORE_MSM || op == OP_STORE_SHARED || op == OP_STORE_LEFT; };
+        std::vector<Val> inv_nodes;
+        for (size_t i = 0; i < n; ++i) if (nodes[i].op == OP_INV) inv_nodes.push_back((Val)i);
+        // the compute nodes v has to wait for: its operands, and for a status-reading store the inversions
+        auto deps = [&](Val v) -> std::vector<Val> {
+            std::vector<Val> d;
+            for (int j = 0; j < n_operands(nodes[v]); ++j) { const Val u = operand(v, j); if (is_compute(u) && distinct(v, j)) d.push_back(u); }
+            if (reads_status(v)) for (Val u : inv_nodes) if (std::find(d.begin(), d.end(), u) == d.end()) d.push_back(u);
+            return d;
+        };
         // longest path to the end (compute nodes)
         std::vector<double> bl(n, 0.0);
         std::vector<std::vector<Val>> succ(n);
-        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) for (int j = 0; j < n_operands(nodes[i]); ++j) { const Val v = operand((Val)i, j); if (is_compute(v) && distinct((Val)i, j)) succ[v].push_back((Val)i); }
+        for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) for (Val v : deps((Val)i)) succ[v].push_back((Val)i);
         for (size_t i = n; i-- > 0;) if (is_compute((Val)i)) { double m = 0; for (Val sc : succ[i]) m = std::max(m, bl[sc]); bl[i] = m + op_weight(nodes[i]); }
         struct Item { int kind; Val v; double fin; };   // 0: compute node, 1: private load / constant, 2: barrier; fin: scheduled finish time
         std::vector<std::vector<Item>> items(K);
@@ -341,8 +356,7 @@ struct Builder {
         auto is_store = [&](Val v) { const uint32_t op = nodes[v].op; return op == OP_STORE_MSM || op == OP_STORE_SHARED || op == OP_STORE_LEFT || op == OP_STORE_GUARD; };
         for (size_t i = 0; i < n; ++i) if (is_compute((Val)i)) {
             ++left;
-            int m = 0;
-            for (int j = 0; j < n_operands(nodes[i]); ++j) if (is_compute(operand((Val)i, j)) && distinct((Val)i, j)) ++m;
+            const int m = (int)deps((Val)i).size();
             missing[i] = m;
             if (!m) ready.push_back((Val)i);
         }
@@ -350,7 +364,7 @@ struct Builder {
         std::vector<size_t> last_bar(K, 0);      // index of the stream's last barrier item + 1 (0: none): a new barrier goes behind it
         uint32_t bars = 0;
         Val last_node = (Val)-1;
-        static const double SLACK = getenv("H2V_FRVM_SLACK") ? atof(getenv("H2V_FRVM_SLACK")) : 0.0;
+        const double SLACK = 0.0;   // extra products a stream may idle before a node is moved to another one (swept in round 2: no gain)
         // Where stream q could start v: at its own clock — or, if an operand sits in another stream behind no barrier yet, after a
         // NEW barrier.  A barrier is one item in every stream: at the end of q; in a stream that holds such an operand, behind the
         // last of them; in every other stream anywhere behind its previous barrier — and in both cases not before the first item
@@ -359,10 +373,8 @@ struct Builder {
         auto place = [&](Val v, int q) -> Place {
             Place pl{false, {}, clk[q]};
             std::vector<size_t> lo(K, 0);
-            for (int j = 0; j < n_operands(nodes[v]); ++j) {
-                const Val u = operand(v, j);
-                if (is_compute(u) && stream_of[u] != q && bar_at[u] == bars) { pl.bar = true; lo[stream_of[u]] = std::max(lo[stream_of[u]], pos[u] + 1); }
-            }
+            for (Val u : deps(v))
+                if (stream_of[u] != q && bar_at[u] == bars) { pl.bar = true; lo[stream_of[u]] = std::max(lo[stream_of[u]], pos[u] + 1); }
             if (!pl.bar) return pl;
             pl.p.assign(K, 0);
             double tb = clk[q];
@@ -434,10 +446,15 @@ struct Builder {
                 ++bars;
             }
             append(q, v);
-            // its stores at once, on the same stream: they free the slot and need no barrier
+            // its stores at once, on the same stream: they free the slot and need no barrier — unless something else the store waits for
+            // (its value when it was the inversion that completed, or the inversion) sits in another stream with no barrier behind it yet
             std::vector<Val> now_ready;
             for (Val sc : succ[v]) if (--missing[sc] == 0) now_ready.push_back(sc);
-            for (Val sc : now_ready) { if (is_store(sc)) append(q, sc); else ready.push_back(sc); }
+            for (Val sc : now_ready) {
+                bool direct = is_store(sc);
+                if (direct) for (Val u : deps(sc)) if (stream_of[u] != q && bar_at[u] == bars) direct = false;
+                if (direct) append(q, sc); else ready.push_back(sc);
+            }
         }
         makespan_k = *std::max_element(clk.begin(), clk.end());
         // ---- slots.  Value ids: compute node v -> v; private load / constant u of stream q -> n * (1 + q) + u
@@ -543,9 +560,8 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     if (total_inst > (1u << 20)) { err = "more than 2^20 instance values per proof are not supported by this build"; return H2V_ERR_INSTANCE_TOO_LARGE; }
     for (size_t l : col_lens) if (l > n) { err = "instance column longer than the domain"; return H2V_ERR_INSTANCE_TOO_LARGE; }
     plan.col_lens = col_lens; plan.n_instance_values = (uint32_t)total_inst;
-    {   // H2V_WIDE_INSTANCES overrides the threshold (tests force the kernel path on small circuits with 0)
-        size_t threshold = 1024;
-        if (const char* e = getenv("H2V_WIDE_INSTANCES")) threshold = (size_t)strtoull(e, nullptr, 10);
+    {   // h2v_options.instance_kernel_threshold overrides the bound (tests force the kernel path on small circuits with 1)
+        const size_t threshold = opts.instance_kernel_threshold > 0 ? (size_t)opts.instance_kernel_threshold - 1 : 1024;
         plan.wide_instances = total_inst > threshold;
     }
 
@@ -1057,26 +1073,8 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     for (uint32_t s2 = 0; s2 < np; ++s2) if (left_scalar[s2] != (Val)-1) b.store_left(b.mul(left_scalar[s2], mult), s2);
 
     b.emit(plan.code, plan.n_slots);
-    for (int K = 2; K <= FRVM_MAX_STREAMS; ++K) b.emit_streams(K, plan.code_k[K - 2], plan.n_slots_k[K - 2]);
-    if (getenv("H2V_DUMP_PLAN")) {   // diagnostic: size and instruction mix of the compiled Fr program
-        std::map<uint32_t, size_t> hist;
-        for (const VmInstr& in : plan.code) ++hist[in.op];
-        fprintf(stderr, "[h2v plan] %zu instructions, %u slots, %zu constants, %zu stream bytes, %u points, %u shared bases; ops:", plan.code.size(), plan.n_slots,
-                b.consts.size(), plan.stream.size(), plan.n_points, plan.n_shared);
-        for (auto& kv : hist) fprintf(stderr, " %u:%zu", kv.first, kv.second);
-        fprintf(stderr, "\n");
-        // the DAG's work and critical path in units of one Fr product (how much a second instruction stream per proof could gain)
-        auto weight = [](const Node& nd) -> double {
-            switch (nd.op) {
-                case OP_MUL: return 1.0;
-                case OP_ADD: case OP_SUB: case OP_NEG: return 0.15;
-                case OP_INV: return 60.0;
-                case OP_POW: { double w = 0; for (uint32_t e = nd.imm; e > 1; e >>= 1) w += 1.5; return w; }
-                case OP_SQRN: return (double)nd.imm;
-                case OP_CONST: return 0.0;
-                default: return 0.5;   // loads (from_raw) and stores (to_raw)
-            }
-        };
+    for (int K = 2; K <= FRVM_MAX_STREAMS; ++K) { b.emit_streams(K, plan.code_k[K - 2], plan.n_slots_k[K - 2]); plan.makespan_k[K - 2] = b.makespan_k; }
+    {   // diagnostics kept with the plan (tests/cpp/plan_host.hip prints them): the DAG's work and critical path in units of one Fr product
         std::vector<double> depth(b.nodes.size(), 0.0);
         double work = 0, cp = 0;
         for (size_t i = 0; i < b.nodes.size(); ++i) {
@@ -1086,18 +1084,11 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
             const bool one = two || nd.op == OP_NEG || nd.op == OP_INV || nd.op == OP_POW || nd.op == OP_SQRN || nd.op == OP_STORE_MSM || nd.op == OP_STORE_SHARED || nd.op == OP_STORE_LEFT || nd.op == OP_STORE_GUARD;
             if (one) d0 = depth[nd.a];
             if (two) d0 = std::max(d0, depth[nd.b]);
-            depth[i] = d0 + weight(nd);
-            work += weight(nd); cp = std::max(cp, depth[i]);
+            const double w = nd.op == OP_CONST ? 0.0 : Builder::op_weight(nd);
+            depth[i] = d0 + w;
+            work += w; cp = std::max(cp, depth[i]);
         }
-        fprintf(stderr, "[h2v plan] DAG work %.1f products, critical path %.1f (%zu nodes)\n", work, cp, b.nodes.size());
-        for (int K = 2; K <= FRVM_MAX_STREAMS; ++K) {
-            std::vector<VmInstr> tmp[FRVM_MAX_STREAMS]; uint32_t ns = 0;
-            b.emit_streams(K, tmp, ns);
-            size_t bars = 0; for (const VmInstr& in : tmp[0]) if (in.op == OP_BARRIER) ++bars;
-            fprintf(stderr, "[h2v plan] %d streams: estimated makespan %.1f, %zu barriers, %u slots; work per stream:", K, b.makespan_k, bars, ns);
-            for (int q = 0; q < K; ++q) { double w = 0; for (const VmInstr& in : tmp[q]) if (in.op != OP_BARRIER) { Node nd{in.op, 0, 0, in.b, false}; w += Builder::op_weight(nd); } fprintf(stderr, " %.0f", w); }
-            fprintf(stderr, "\n");
-        }
+        plan.dag_work = work; plan.dag_critical_path = cp;
     }
     plan.consts = b.consts;
     // LOAD_CHAL immediates already refer to squeeze order
@@ -1159,7 +1150,7 @@ int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens_in, PlanDevic
     if (it != ctx->vk->plans.end()) { *out = it->second; return 0; }
     PlanDevice* pd = new PlanDevice();
     std::string err;
-    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript; po.circuit_instances = ctx->circuit_instances; po.guard_terms = guard_terms;
+    PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript; po.circuit_instances = ctx->circuit_instances; po.guard_terms = guard_terms; po.instance_kernel_threshold = ctx->instance_kernel_threshold;
     int rc = compile_plan(ctx->vk->vk, ctx->params, col_lens, po, pd->host, err);
     if (rc) { set_last_error("plan: " + err); delete pd; return rc; }
     H2V_HIP_CHECK(hipSetDevice(ctx->device));

@@ -44,8 +44,15 @@ class TranscriptKind(enum.IntEnum):  # the `T: TranscriptRead` parameter (lib.rs
     Keccak256 = 1
 
 
-class _Options(ctypes.Structure):
-    _fields_ = [("multiopen", ctypes.c_int), ("transcript", ctypes.c_int), ("circuit_instances", ctypes.c_int)]
+class _Options(ctypes.Structure):   # h2v_options
+    _fields_ = [("struct_size", ctypes.c_size_t), ("multiopen", ctypes.c_int), ("transcript", ctypes.c_int), ("circuit_instances", ctypes.c_int),
+                ("instance_kernel_threshold", ctypes.c_int)]
+
+
+class _Tuning(ctypes.Structure):    # h2v_tuning (debug / test): forced kernel variants, 0 = automatic
+    _fields_ = [("struct_size", ctypes.c_size_t)] + [(k, ctypes.c_int) for k in (
+        "frvm_streams", "frvm_lds_kb", "msm_parts", "msm_global_sort", "msm_no_term_split", "msm_window_threads", "msm_window_wpw",
+        "msm_window_slots", "msm_affine", "pairing_one_stream")]
 
 
 class ParamsKZG:
@@ -136,14 +143,14 @@ class Context:
     """ParamsKZG + VerifyingKey resident on one GPU (h2v_ctx)."""
 
     def __init__(self, params: ParamsKZG, vk: VerifyingKey = None, device: int = 0, multiopen=MultiOpen.SHPLONK,
-                 transcript=TranscriptKind.Blake2b, circuit_instances: int = 1):
+                 transcript=TranscriptKind.Blake2b, circuit_instances: int = 1, instance_kernel_threshold: int = 0):
         """circuit_instances = len(instances) of the reference's verify_proof (`instances: &[&[&[Fr]]]`, lib.rs:43): how many
         circuit instances share one proof transcript.  With M > 1 the `instances` of a proof is the list of its M x columns,
         instance by instance."""
         self._lib = _lib.load_library()
         self._h = ctypes.c_void_p()
         vkb = vk.data if vk is not None else None
-        opts = _Options(int(multiopen), int(transcript), int(circuit_instances))
+        opts = _Options(ctypes.sizeof(_Options), int(multiopen), int(transcript), int(circuit_instances), int(instance_kernel_threshold))
         self.circuit_instances = int(circuit_instances)
         check(self._lib.h2v_ctx_create_ex(params.data, len(params.data), int(params.format), vkb, len(vkb) if vkb else 0,
                                           int(vk.format) if vk is not None else 0, device, ctypes.byref(opts), ctypes.byref(self._h)))
@@ -159,6 +166,20 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_tuning(self, **fields):
+        """Debug / test (h2v_ctx_set_tuning): force kernel variants the library otherwise chooses from the launch shape, e.g.
+        set_tuning(frvm_streams=2, msm_window_slots=3).  No arguments = back to automatic.  Not synchronised with launches in
+        flight: call while the context is idle."""
+        if not fields:
+            check(self._lib.h2v_ctx_set_tuning(self._h, None))
+            return
+        t = _Tuning(ctypes.sizeof(_Tuning))
+        for k, val in fields.items():
+            if k == "struct_size" or not hasattr(t, k):
+                raise ValueError(f"unknown tuning field {k!r}")
+            setattr(t, k, int(val))
+        check(self._lib.h2v_ctx_set_tuning(self._h, ctypes.byref(t)))
 
     # -- MSMKZG::eval (poly/kzg/msm.rs:81-86)
     def msm_g1(self, scalars, bases):

@@ -76,8 +76,19 @@ int h2v_ctx_create(const uint8_t* params, size_t params_len, int params_format,
  *                      passes).  With M > 1 a proof carries M sets of advice / permutation / lookup / shuffle commitments and
  *                      evaluations in the reference's interleaved order (lib.rs:91-161, 220-253), and every entry point below takes
  *                      n_instance_columns = M x the VK's instance columns, col_lens and instances32 instance-major.
- * h2v_ctx_create == h2v_ctx_create_ex with {0, 0, 1}. */
-typedef struct h2v_options { int multiopen; int transcript; int circuit_instances; } h2v_options;
+ *                      (Parity for M > 1 is pinned by the repository's two restatements only — oracle/ and oracle/pyref.py,
+ *                      the _m2 fixtures under tests/golden — no caller inside the reference passes M > 1.)
+ *   struct_size:       sizeof(h2v_options) as the CALLER's header declares it.  The library reads only the fields that lie inside
+ *                      it (later fields default to 0), and rejects a value that is not a layout it knows with H2V_ERR_BAD_ARGUMENT:
+ *                      a caller built against another revision of this struct gets an error, not another proof layout.
+ *   instance_kernel_threshold: debug / test.  0 = the default: instance columns of more than 1024 values in total are summed by the
+ *                      wide-instance kernel instead of being unrolled into the per-proof program; n > 0 sets that bound to n - 1
+ *                      (1 = every circuit takes the kernel path).
+ * h2v_ctx_create == h2v_ctx_create_ex with {sizeof(h2v_options), 0, 0, 1, 0}. */
+typedef struct h2v_options { size_t struct_size; int multiopen; int transcript; int circuit_instances; int instance_kernel_threshold; } h2v_options;
+#define H2V_OPTIONS_INIT { sizeof(h2v_options), 0, 0, 1, 0 }
+#define H2V_ABI_VERSION 3   /* bumped whenever a struct of this header changes layout; h2v_abi_version() returns the library's */
+int h2v_abi_version(void);
 #define H2V_MULTIOPEN_SHPLONK 0
 #define H2V_MULTIOPEN_GWC 1
 #define H2V_TRANSCRIPT_BLAKE2B 0
@@ -85,6 +96,28 @@ typedef struct h2v_options { int multiopen; int transcript; int circuit_instance
 int h2v_ctx_create_ex(const uint8_t* params, size_t params_len, int params_format,
                       const uint8_t* vk, size_t vk_len, int vk_format,
                       int device, const h2v_options* options, h2v_ctx** out);
+/* Debug / test: force the kernel variants that the library otherwise chooses from the shape of a launch (how many proofs, groups,
+ * MSM terms it carries).  Every field 0 = automatic, which is what production runs; the library reads no environment variable.
+ * The bit-exact suite uses this to put every variant under test at sizes the CPU oracle can follow.  The setting belongs to the
+ * context and is read when a launch is enqueued; it is NOT synchronised with launches of other threads (set it while the context is
+ * idle).  A NULL pointer restores automatic choice.
+ *   frvm_streams        1..4: instruction streams per proof of the Fr program (automatic: 4 up to 341 waves per launch, else 2)
+ *   frvm_lds_kb         LDS slice for the program's slots, KB (automatic: 156 / 78 / 36 by launch size)
+ *   msm_parts           pieces the accumulators are left in for the pairing (automatic: 6); 1 = whole points (full Horner, whole-point pairing)
+ *   msm_global_sort     1: the global counting sort instead of the per-window LDS sort
+ *   msm_no_term_split   1: do not cut problems of more than 16 384 terms into sub-problems
+ *   msm_window_threads  lanes per window reduction (64, 128, 256; automatic by bucket and window count)
+ *   msm_window_wpw      windows per workgroup of the window reduction (1, 2, 4)
+ *   msm_window_slots    3: the 20 KB form of the window reduction without the two-bit digit table (automatic: beyond 1024 windows)
+ *   msm_affine          1: force / 2: forbid the batched-affine bucket accumulation (automatic: by entries per bucket)
+ *   pairing_one_stream  1: the single-stream pairing table over split accumulators instead of the two-stream one */
+typedef struct h2v_tuning {
+    size_t struct_size;
+    int frvm_streams, frvm_lds_kb;
+    int msm_parts, msm_global_sort, msm_no_term_split, msm_window_threads, msm_window_wpw, msm_window_slots, msm_affine;
+    int pairing_one_stream;
+} h2v_tuning;
+int h2v_ctx_set_tuning(h2v_ctx* ctx, const h2v_tuning* tuning);
 void h2v_ctx_destroy(h2v_ctx* ctx);
 
 /* Shape of one proof for this VK (Np points, Ns scalars, T_R right-channel terms). */

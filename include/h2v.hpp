@@ -64,7 +64,8 @@ class Context {
 public:
     Context(const ParamsKZG& p, const VerifyingKey& vk, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b,
             int circuit_instances = 1) {
-        h2v_options o{(int)mo, (int)tr, circuit_instances};
+        h2v_options o = H2V_OPTIONS_INIT;
+        o.multiopen = (int)mo; o.transcript = (int)tr; o.circuit_instances = circuit_instances;
         check(h2v_ctx_create_ex(p.bytes.data(), p.bytes.size(), (int)p.format, vk.bytes.data(), vk.bytes.size(), (int)vk.format, device, &o, &h_));
     }
     ~Context() { if (h_) h2v_ctx_destroy(h_); }

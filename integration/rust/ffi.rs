@@ -7,9 +7,15 @@ use core::ffi::{c_char, c_float, c_int, c_void};
 
 #[repr(C)] pub struct h2v_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct h2v_batch { _p: [u8; 0] }
+/// struct_size: `core::mem::size_of::<h2v_options>()` (the library rejects a layout it does not know);
 /// multiopen: VerifierSHPLONK / VerifierGWC; transcript: Blake2bRead / Keccak256Read; circuit_instances: `instances.len()` of
-/// verify_proof (0 or 1 = one circuit instance per transcript)
-#[repr(C)] pub struct h2v_options { pub multiopen: c_int, pub transcript: c_int, pub circuit_instances: c_int }
+/// verify_proof (0 or 1 = one circuit instance per transcript); instance_kernel_threshold: debug, 0 = default
+#[repr(C)] pub struct h2v_options { pub struct_size: usize, pub multiopen: c_int, pub transcript: c_int, pub circuit_instances: c_int, pub instance_kernel_threshold: c_int }
+/// debug / test: forced kernel variants, every field 0 = automatic (h2v_ctx_set_tuning)
+#[repr(C)] pub struct h2v_tuning { pub struct_size: usize, pub frvm_streams: c_int, pub frvm_lds_kb: c_int, pub msm_parts: c_int, pub msm_global_sort: c_int,
+                                   pub msm_no_term_split: c_int, pub msm_window_threads: c_int, pub msm_window_wpw: c_int, pub msm_window_slots: c_int,
+                                   pub msm_affine: c_int, pub pairing_one_stream: c_int }
+pub const H2V_ABI_VERSION: c_int = 3;
 
 pub const H2V_OK: c_int = 0;
 pub const H2V_ERR_INVALID_INSTANCES: c_int = -1;
@@ -46,6 +52,8 @@ extern "C" {
     pub fn h2v_ctx_create_ex(params: *const u8, params_len: usize, params_format: c_int, vk: *const u8, vk_len: usize, vk_format: c_int,
                              device: c_int, options: *const h2v_options, out: *mut *mut h2v_ctx) -> c_int;
     pub fn h2v_ctx_destroy(ctx: *mut h2v_ctx);
+    pub fn h2v_abi_version() -> c_int;
+    pub fn h2v_ctx_set_tuning(ctx: *mut h2v_ctx, tuning: *const h2v_tuning) -> c_int;
     pub fn h2v_ctx_proof_shape(ctx: *const h2v_ctx, proof_len: *mut usize, n_points: *mut usize, n_scalars: *mut usize,
                                n_right_terms: *mut usize, n_instance_columns: *mut usize) -> c_int;
     pub fn h2v_msm_g1(ctx: *mut h2v_ctx, scalars32: *const u8, bases64: *const u8, n: usize, out_xy: *mut u8, out_is_identity: *mut c_int) -> c_int;

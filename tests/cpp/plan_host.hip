@@ -3,7 +3,9 @@
 //   (1) race freedom — inside one barrier epoch no stream writes a slot that another stream reads or writes (the streams of a proof
 //       run in different waves: only a barrier orders them), and the streams hold the same number of barriers;
 //   (2) equivalence — evaluated symbolically (hash-consed expression ids), every STORE of the multi-stream program writes the same
-//       expression to the same place as the single-stream program, and nothing is stored twice or left out.
+//       expression to the same place as the single-stream program, and nothing is stored twice or left out;
+//   (3) status order — every store that reads the proof's status word (STORE_MSM / STORE_SHARED / STORE_LEFT zero a failed proof's
+//       scalars) runs after every OP_INV (which sets it when the reference would panic): later in the same stream, or behind a barrier.
 // Usage: plan_host <vk file> <params file> <multiopen> <transcript> <circuit_instances> <guard 0|1> <col_len>...
 // Build (tests/test_plan_streams.py): hipcc -O1 -std=c++17 --offload-arch=gfx950 plan_host.hip ../../halo2_verifier_amd/csrc/vkplan.hip ../../halo2_verifier_amd/csrc/params.hip
 #include <cstdio>
@@ -138,6 +140,20 @@ int main(int argc, char** argv) {
             // (2) race free, so any interleaving of the epoch's streams gives the same values: one stream after the other
             for (int q = 0; q < K; ++q) for (const VmInstr& in : ep[q][e]) if (!step(sym, in, slots, got, err)) { fprintf(stderr, "K=%d stream %d epoch %zu: %s\n", K, q, e, err.c_str()); return 1; }
         }
+        // (3) every status-reading store behind every inversion
+        {
+            std::vector<std::pair<int, size_t>> inv_at;   // (stream, epoch) of every OP_INV, with its index inside the epoch
+            std::vector<size_t> inv_idx;
+            for (int q = 0; q < K; ++q) for (size_t e = 0; e < n_epochs; ++e) for (size_t i = 0; i < ep[q][e].size(); ++i) if (ep[q][e][i].op == OP_INV) { inv_at.push_back({q, e}); inv_idx.push_back(i); }
+            for (int q = 0; q < K; ++q) for (size_t e = 0; e < n_epochs; ++e) for (size_t i = 0; i < ep[q][e].size(); ++i) {
+                const uint32_t op = ep[q][e][i].op;
+                if (op != OP_STORE_MSM && op != OP_STORE_SHARED && op != OP_STORE_LEFT) continue;
+                for (size_t k = 0; k < inv_at.size(); ++k) {
+                    const bool ordered = inv_at[k].second < e || (inv_at[k].second == e && inv_at[k].first == q && inv_idx[k] < i);
+                    if (!ordered) { fprintf(stderr, "K=%d: a status-reading store (stream %d, epoch %zu) is not ordered behind the inversion of stream %d, epoch %zu\n", K, q, e, inv_at[k].first, inv_at[k].second); return 1; }
+                }
+            }
+        }
         if (got != want) {
             fprintf(stderr, "K=%d: the stores differ from the single-stream program's (%zu vs %zu)\n", K, got.size(), want.size());
             return 1;
@@ -146,5 +162,6 @@ int main(int argc, char** argv) {
         printf("K=%d ok: %zu instructions, %zu barriers, %u slots, %zu stores\n", K, n_instr, n_epochs - 1, plan.n_slots_k[K - 2], got.size());
     }
     printf("single ok: %zu instructions, %u slots\n", plan.code.size(), plan.n_slots);
+    printf("dag: work %.1f products, critical path %.1f; estimated makespan with 2 / 3 / 4 streams: %.1f / %.1f / %.1f\n", plan.dag_work, plan.dag_critical_path, plan.makespan_k[0], plan.makespan_k[1], plan.makespan_k[2]);
     return 0;
 }

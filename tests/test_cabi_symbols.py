@@ -48,8 +48,16 @@ def test_rust_binding_covers_the_header():
     for name, val in re.findall(r"#define (H2V_[A-Z0-9_]+) \(?(-?\d+)\)?", text):
         m = re.search(r"pub const %s: \w+ = (-?\d+);" % name, rs)
         assert m and int(m.group(1)) == int(val), name
-    fields = re.search(r"typedef struct h2v_options \{([^}]*)\}", text).group(1)
-    assert [f.split()[-1] for f in fields.split(";") if f.strip()] == re.findall(r"pub (\w+): c_int", re.search(r"pub struct h2v_options \{([^}]*)\}", rs).group(1))
+    for struct in ("h2v_options", "h2v_tuning"):
+        fields = re.search(r"typedef struct %s \{([^}]*)\}" % struct, text).group(1)
+        c_names = [n.strip() for decl in fields.split(";") if decl.strip() for n in decl.split(None, 1)[1].split(",")]
+        assert c_names == re.findall(r"pub (\w+): \w+", re.search(r"pub struct %s \{([^}]*)\}" % struct, rs).group(1)), struct
+    # the ctypes mirrors have the same fields in the same order
+    from halo2_verifier_amd import verifier
+    for struct, cls in (("h2v_options", verifier._Options), ("h2v_tuning", verifier._Tuning)):
+        fields = re.search(r"typedef struct %s \{([^}]*)\}" % struct, text).group(1)
+        c_names = [n.strip() for decl in fields.split(";") if decl.strip() for n in decl.split(None, 1)[1].split(",")]
+        assert c_names == [f[0] for f in cls._fields_], struct
 
 
 def test_error_codes_mirror_plonk_error():
@@ -88,6 +96,37 @@ def test_product_does_not_link_or_import_the_oracle():
                         # comments that say "shares no code with oracle/" are the only allowed mentions
                         lines = [l for l in text.splitlines() if needle in l and not l.strip().startswith(("//", "#", "*", '"""')) and "no code with oracle" not in l]
                         assert not lines, (f, lines)
+
+
+def test_product_reads_no_environment_variable():
+    """The environment of a proof verifier must not select its code path: kernel variants are chosen from the launch shape, and
+    forced only through h2v_ctx_set_tuning / h2v_options (debug fields of the C ABI)."""
+    pkg = os.path.join(ROOT, "halo2_verifier_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(pkg, f), errors="replace"), 1):
+                if "getenv" in line:
+                    hits.append(f"{f}:{i}")
+    assert not hits, hits
+    out = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(pkg, "build", "libh2v_amd.so")], capture_output=True, text=True).stdout
+    assert "getenv" not in out
+
+
+def test_options_struct_size_guards_the_layout(lib):
+    """h2v_ctx_create_ex rejects an h2v_options whose struct_size is not a layout the library knows (a caller built against another
+    revision of the header), before it looks at any other argument that needs a device."""
+    from halo2_verifier_amd import verifier
+    lib.h2v_abi_version.restype = ctypes.c_int
+    assert lib.h2v_abi_version() == 3
+    lib.h2v_last_error.restype = ctypes.c_char_p
+    srs = open(os.path.join(ROOT, "tests", "golden", "kzg_bn254_8.srs"), "rb").read()
+    params = srs[:4] + srs[4:68] + srs[-256:]
+    for bad in (0, 12, ctypes.sizeof(verifier._Options) + 8):
+        o = verifier._Options(bad, 0, 0, 1, 0)
+        h = ctypes.c_void_p()
+        rc = lib.h2v_ctx_create_ex(params, ctypes.c_size_t(len(params)), 1, None, ctypes.c_size_t(0), 0, 0, ctypes.byref(o), ctypes.byref(h))
+        assert rc == -16 and b"struct_size" in lib.h2v_last_error()
 
 
 def test_cpp_mirror_header_compiles():

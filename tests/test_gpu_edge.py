@@ -197,9 +197,9 @@ def test_80000_public_inputs_at_k18():
     ctx.close(); s.free(); s8.free()
 
 
-def test_instance_kernel_path_equals_program_path(monkeypatch):
+def test_instance_kernel_path_equals_program_path():
     """Wide instance vectors are evaluated by k_instance_eval instead of being unrolled into the Fr program; the threshold
-    (H2V_WIDE_INSTANCES, read when a plan is compiled) is forced to 0 here so that small circuits take the kernel path too:
+    (h2v_options.instance_kernel_threshold, read when a plan is compiled) is forced to 1 here so that small circuits take the kernel path too:
     same challenges, Guard, accumulators and verdicts as the program path and as the oracle, for an odd column length,
     a tampered input and a lookup circuit."""
     import random
@@ -217,12 +217,8 @@ def test_instance_kernel_path_equals_program_path(monkeypatch):
         I2[1] = [[circuits.le32(123)] + I[1][0][1:]]
         rand = [rnd.randrange(1, R_MOD) for _ in range(len(P))]
         results = []
-        for env in (None, "0"):
-            if env is None:
-                monkeypatch.delenv("H2V_WIDE_INSTANCES", raising=False)
-            else:
-                monkeypatch.setenv("H2V_WIDE_INSTANCES", env)
-            ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes))
+        for threshold in (0, 1):
+            ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes), instance_kernel_threshold=threshold)
             results.append((ctx.verify_batch(P, I, rand), ctx.verify_batch(P, I2, rand), ctx.verify_each(P, I2), ctx.guard_msm(P[0], I[0])))
             ctx.close()
         assert results[0] == results[1]

@@ -47,7 +47,7 @@ def test_msm_matches_oracle(ctx, srs, oracle, n):
 
 
 @pytest.mark.parametrize("n", [16384, 16385, 40000])
-def test_msm_large_problem_is_cut(ctx, srs, oracle, n, monkeypatch):
+def test_msm_large_problem_is_cut(ctx, srs, oracle, n):
     """More terms than one per-window LDS sort takes (16 384): the problem is cut into sub-problems whose window sums are merged
     (csrc/msm.hip: msm_merge_windows).  Same bytes as the oracle, and as the uncut form (global counting sort)."""
     rnd = random.Random(7000 + n)
@@ -60,8 +60,11 @@ def test_msm_large_problem_is_cut(ctx, srs, oracle, n, monkeypatch):
     bases[9] = bytes(64)
     exp = oracle_lib.g1_msm(oracle, scalars, bases)
     assert ctx.msm_g1(scalars, bases) == exp
-    monkeypatch.setenv("H2V_MSM_NO_TERM_SPLIT", "1")
-    assert ctx.msm_g1(scalars, bases) == exp
+    ctx.set_tuning(msm_no_term_split=1)
+    try:
+        assert ctx.msm_g1(scalars, bases) == exp
+    finally:
+        ctx.set_tuning()
 
 
 def test_msm_large_skewed_problem(ctx, srs, oracle):

@@ -3,11 +3,10 @@
 A launch that ends in its own pairing checks leaves every accumulator as `parts` points,
     acc = sum_j 2^(shift j) piece_j,
 and checks  prod_j e(L_j, 2^(shift j) s_g2) e(R_j, -2^(shift j) g2) == 1  against tables of G2 multiples built on the host,
-while the whole points are put together beside the pairing.  Whatever the number of pieces (H2V_MSM_PARTS, read per launch;
+while the whole points are put together beside the pairing.  Whatever the number of pieces (h2v_tuning.msm_parts, read per launch;
 1 = the unsplit path), verdicts, per-proof statuses and the evaluated accumulator channels must be the oracle's, bit for
 bit — for accepted batches, for a batch whose pairing fails, with a rejected proof inside, for grouped launches, for one proof
 per check (SingleStrategy) and for both multi-open schemes (different window plans, i.e. different shifts)."""
-import os
 import random
 
 import pytest
@@ -20,19 +19,17 @@ pytestmark = pytest.mark.gpu
 PARTS = [1, 2, 3, 4, 5, 6]
 
 
-class _parts:
-    def __init__(self, p):
-        self.p = p
+class _tuned:
+    """Forced kernel variants (h2v_ctx_set_tuning) for the launches inside the block; automatic choice again afterwards."""
+
+    def __init__(self, ctx, **fields):
+        self.ctx, self.fields = ctx, fields
 
     def __enter__(self):
-        self.old = os.environ.get("H2V_MSM_PARTS")
-        os.environ["H2V_MSM_PARTS"] = str(self.p)
+        self.ctx.set_tuning(**self.fields)
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("H2V_MSM_PARTS", None)
-        else:
-            os.environ["H2V_MSM_PARTS"] = self.old
+        self.ctx.set_tuning()
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +55,7 @@ def test_every_part_count_matches_the_oracle(pool):
         exp = circuits.oracle_verify_batch(s, P[:n], I[:n], rand)
         assert exp[0] is True
         for parts in PARTS:
-            with _parts(parts):
+            with _tuned(ctx, msm_parts=parts):
                 assert ctx.verify_batch(P[:n], I[:n], rand) == exp, (n, parts)
     ctx.close()
 
@@ -78,7 +75,7 @@ def test_failing_pairing_and_rejected_proof(pool):
     exp_rej = circuits.oracle_verify_batch(s, P_rej, I[:n], rand)
     assert exp_rej[0] is False and exp_rej[1][11] != 0
     for parts in PARTS:
-        with _parts(parts):
+        with _tuned(ctx, msm_parts=parts):
             assert ctx.verify_batch(P[:n], I_bad, rand) == exp_bad, parts
             assert ctx.verify_batch(P_rej, I[:n], rand) == exp_rej, parts
     ctx.close()
@@ -96,7 +93,7 @@ def test_grouped_launch_and_single_strategy(pool):
     flat, inst = b"".join(P[:n]), b"".join(b"".join(col) for i in I2 for col in i)
     results = []
     for parts in (1, 3, 6):
-        with _parts(parts):
+        with _tuned(ctx, msm_parts=parts):
             b = h2v.Batch(ctx, n, 8, groups=G)
             b.upload(flat, 1024, inst, [8], b"".join(r.to_bytes(32, "little") for r in rand))
             b.launch(with_pairing=True)
@@ -126,38 +123,21 @@ def test_gwc_plan_has_its_own_shift():
     exp = circuits.oracle_verify_batch(s, P, I, rand)
     assert exp[0] is True
     for parts in (1, 2, 6):
-        with _parts(parts):
+        with _tuned(ctx, msm_parts=parts):
             assert ctx.verify_batch(P, I, rand) == exp, parts
     ctx.close()
     s.free()
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
-@pytest.mark.parametrize("knobs", [dict(H2V_PAIRING_ONE_STREAM="1"), dict(H2V_FRVM_ONE_STREAM="1"), dict(H2V_PAIRING_ONE_STREAM="1", H2V_FRVM_ONE_STREAM="1"),
-                                   dict(H2V_MSM_GLOBAL_SORT="1"), dict(H2V_MSM_PARTS="1", H2V_FRVM_ONE_STREAM="1")])
+@pytest.mark.parametrize("knobs", [dict(pairing_one_stream=1), dict(frvm_streams=1), dict(pairing_one_stream=1, frvm_streams=1), dict(frvm_streams=2), dict(frvm_streams=3),
+                                   dict(frvm_streams=2, frvm_lds_kb=36), dict(frvm_streams=4, frvm_lds_kb=78), dict(msm_global_sort=1), dict(msm_parts=1, frvm_streams=1),
+                                   dict(msm_window_threads=64, msm_window_slots=3), dict(msm_window_threads=64, msm_window_wpw=2), dict(msm_window_threads=128, msm_window_wpw=2),
+                                   dict(msm_window_threads=256)])
 def test_single_stream_and_fallback_kernels_stay_exact(pool, knobs):
     """The default path runs the Fr program and the pairing as two instruction streams each and sorts inside LDS; the single-stream
     interpreter, the single-stream pairing table over merged lines, the whole-point pairing and the global counting sort remain in
-    the library (other launch shapes, knobs) — same verdicts, statuses and accumulator bytes as the oracle through every one."""
+    the library (other launch shapes; forced here through h2v_ctx_set_tuning) — and so do the Fr program with two and three streams and small
+    LDS slices (what a throughput launch runs) and the window reduction's other shapes — same verdicts, statuses and accumulator bytes as the oracle through every one."""
     s, P, I = pool
     n = 40
     rnd = random.Random(11)
@@ -169,7 +149,7 @@ def test_single_stream_and_fallback_kernels_stay_exact(pool, knobs):
     exp_rej = circuits.oracle_verify_batch(s, P_rej, I[:n], rand)
     assert exp[0] is True and exp_bad[0] is False
     ctx = _ctx(s)
-    with _env(**knobs):
+    with _tuned(ctx, **knobs):
         assert ctx.verify_batch(P[:n], I[:n], rand) == exp
         assert ctx.verify_batch(P[:n], I_bad, rand) == exp_bad
         assert ctx.verify_batch(P_rej, I[:n], rand) == exp_rej
