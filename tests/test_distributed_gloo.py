@@ -112,3 +112,67 @@ def test_grouped_accumulators_gather_in_rank_major_order():
     for p in procs: p.join(120)
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=5) is True
+
+
+def _worker_entry(rank, world, port, total, tamper, draw_locally, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits
+    import fake_shard
+    from halo2_verifier_amd import distributed as h2d
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = circuits.setup_vector_mul(8, 10)
+    P, I = circuits.prove_vector_mul_batch(s, total, seed=6, threads=2)
+    if tamper >= 0:
+        b = bytearray(P[tamper]); b[0:32] = b"\xff" * 32; P[tamper] = bytes(b)      # undecodable point: the proof leaves its shard's accumulators
+    rnd = random.Random(77)
+    rand = None if draw_locally else [rnd.randrange(1, R_MOD) for _ in range(total)]
+
+    class Ctx:                      # the stand-in never touches it
+        device = 0
+    got = h2d.verify_batch_sharded(Ctx(), P, I, rand, batch_factory=fake_shard.make_factory(s), device="cpu")
+    if rand is None:
+        # rank 0 drew and broadcast: all ranks must have used the same stream, i.e. report the same accumulators
+        blob = torch.tensor(list(got[2] + got[3]), dtype=torch.uint8)
+        both = [torch.zeros_like(blob) for _ in range(world)]
+        dist.all_gather(both, blob)
+        same = all(bool((b == both[0]).all()) for b in both)
+        if rank == 0:
+            q.put((got[0], got[1], same))
+    else:
+        ref = circuits.oracle_verify_batch(s, P, I, rand)
+        one = h2d.verify_batch_sharded_local(Ctx(), P, I, rand, 3, batch_factory=fake_shard.make_factory(s), device="cpu")
+        q.put((rank, got == ref, one == ref, got[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,tamper", [(7, -1), (6, 4), (1, -1)])
+def test_verify_batch_sharded_entry_point_two_ranks(total, tamper):
+    """distributed.verify_batch_sharded — the product's entry point for a sharded batch — over gloo with two ranks (the device side
+    replaced by tests/fake_shard.py: there is no GPU here): every rank returns the unsharded oracle result, a proof rejected on
+    one shard rejects the batch on every rank, a shard may be empty (1 proof, 2 ranks), and the one-device
+    sequential form (verify_batch_sharded_local, 3 shards) agrees."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_entry, args=(r, 2, port, total, tamper, False, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(300)
+    assert all(p.exitcode == 0 for p in procs)
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert [r[0] for r in res] == [0, 1]
+    assert all(r[1] and r[2] for r in res)
+    assert all(r[3] is (tamper < 0) for r in res)
+
+
+def test_verify_batch_sharded_draws_are_common_when_rank0_draws():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_entry, args=(r, 2, port, 5, -1, True, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(300)
+    assert all(p.exitcode == 0 for p in procs)
+    ok, st, same = q.get(timeout=5)
+    assert ok is True and st == [0] * 5 and same is True

@@ -1,7 +1,8 @@
-"""The N > 1 path on one GPU: R shards of one batch, each run through the staged C ABI with the draw tail of its
-global position (h2v_batch_upload rand32_tail), accumulators exported and folded by h2v_batch_fold_check_enqueue —
-the exact call sequence bench.py issues per rank, minus the RCCL all-gather (covered on gloo by
-tests/test_distributed_gloo.py).  The folded result must equal the unsharded h2v_verify_batch bit for bit, for any R.
+"""The N > 1 path on one GPU: R shards of one batch through halo2_verifier_amd.distributed (ShardedBatch /
+verify_batch_sharded_local): each shard run through the staged C ABI with the draw tail of its global position
+(h2v_batch_upload rand32_tail), accumulators exported and folded by h2v_batch_fold_check_enqueue — the call sequence
+bench.py and verify_batch_sharded issue per rank, minus the all-gather (covered with two real ranks below over gloo, and on
+CPU by tests/test_distributed_gloo.py).  The folded result must equal the unsharded h2v_verify_batch bit for bit, for any R.
 
 Also the BASELINE.json-size checks (1024 proofs): determinism, sharding invariance, and single-proof tampering."""
 import random
@@ -24,34 +25,11 @@ def big():
 
 
 def _sharded(ctx, P, I, rand, R):
-    import torch
-    import halo2_verifier_amd as h2v
+    """R shards on this one GPU through the library's entry point (distributed.verify_batch_sharded_local): the fold is done by
+    shard 0; its verdict alone counts — the exchanged records carry every shard's failed-proof count (H2V_ACC_RECORD_BYTES), so no
+    status AND across shards is needed on the host."""
     from halo2_verifier_amd import distributed as h2d
-    total = len(P)
-    rand_all = b"".join(r.to_bytes(32, "little") for r in rand)
-    acc = torch.zeros(R * h2d.ACC_BYTES, dtype=torch.uint8, device="cuda:0")
-    statuses = []
-    batches = []
-    for r in range(R):
-        lo, hi = h2d.shard_bounds(total, R, r)
-        b = h2v.Batch(ctx, max(hi - lo, 1), 8)
-        flat = b"".join(P[lo:hi])
-        inst = b"".join(b"".join(col) for i in I[lo:hi] for col in i)
-        b.upload(flat, 1024, inst, [8], h2d.tail_for_shard(rand_all, lo))
-        b.launch(with_pairing=False)
-        ok, st, _, _ = b.finish()
-        statuses += st
-        b.export_accumulators(acc.data_ptr() + r * h2d.ACC_BYTES)
-        b.finish()
-        batches.append(b)
-    torch.cuda.synchronize()
-    batches[0].fold_check_enqueue(acc.data_ptr(), R)
-    ok, _, left, right = batches[0].finish()
-    for b in batches:
-        b.close()
-    # `ok` is the FOLDING batch's verdict alone: the exchanged records carry every shard's failed-proof count
-    # (H2V_ACC_RECORD_BYTES), so no status AND across shards is needed on the host
-    return ok, statuses, left, right
+    return h2d.verify_batch_sharded_local(ctx, P, I, rand, R)
 
 
 def _ctx(s):
@@ -239,3 +217,81 @@ def test_rccl_backend_single_rank_smoke(big):
         b.close(); ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_config3_and_5_full_size_through_the_entry_point(big):
+    """BASELINE.json configs 3 and 5 AS STATED, on one GPU: 65 536 proofs (the 1024 distinct ones cycled) as 8 shards of 8192 with the
+    draw tails of their global positions, the 8 records folded, ONE pairing — equal bit for bit to the unsharded 65 536-proof
+    h2v_verify_batch; and a single proof rejected on a NON-folding shard (shard 5) rejects the whole batch."""
+    from halo2_verifier_amd import distributed as h2d
+    s, P, I = big
+    ctx = _ctx(s)
+    n = 65536
+    Pn = [P[i % 1024] for i in range(n)]
+    In = [I[i % 1024] for i in range(n)]
+    rnd = random.Random(65536)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    ref = ctx.verify_batch(Pn, In, rand)
+    assert ref[0] is True and ref[1] == [0] * n
+    got = h2d.verify_batch_sharded_local(ctx, Pn, In, rand, 8)
+    assert got == ref
+    # the same unsharded result from two very different launch shapes: one batch, and the fold of 64 shards of 1024
+    assert h2d.verify_batch_sharded_local(ctx, Pn, In, rand, 64) == ref
+    bad = list(Pn)
+    k = 5 * 8192 + 4097
+    b = bytearray(bad[k]); b[64:96] = b"\xff" * 32; bad[k] = bytes(b)
+    got = h2d.verify_batch_sharded_local(ctx, bad, In, rand, 8)
+    assert got[0] is False and [i for i, v in enumerate(got[1]) if v] == [k] and got[1][k] == -5
+    assert got == ctx.verify_batch(bad, In, rand)
+    ctx.close()
+
+
+def _rank_main(rank, world, port, q):
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import circuits as C
+    import halo2_verifier_amd as h2v
+    from halo2_verifier_amd import distributed as h2d
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # RCCL refuses two ranks on one device: gloo carries the records
+    s = C.setup_vector_mul(8, 8)
+    P, I = C.prove_vector_mul_batch(s, 37, seed=99, threads=4)
+    ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes), device=0)
+    rnd = random.Random(3)
+    rand = [rnd.randrange(1, C.R_MOD) for _ in range(37)]
+    good = h2d.verify_batch_sharded(ctx, P, I, rand)
+    bad = list(P); b = bytearray(bad[30]); b[0:32] = b"\xff" * 32; bad[30] = bytes(b)       # on the last rank's shard
+    rej = h2d.verify_batch_sharded(ctx, bad, I, rand)
+    drawn = h2d.verify_batch_sharded(ctx, P, I, None)                  # rank 0 draws and broadcasts
+    tiny = h2d.verify_batch_sharded(ctx, P[:1], I[:1], rand[:1])       # the last rank's shard is empty
+    ref = (ctx.verify_batch(P, I, rand), ctx.verify_batch(bad, I, rand), ctx.verify_batch(P[:1], I[:1], rand[:1])) if rank == 0 else None
+    q.put((rank, good, rej, drawn, tiny, ref))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_verify_batch_sharded_with_real_ranks_on_one_gpu(world):
+    """distributed.verify_batch_sharded with `world` real ranks (processes), all on cuda:0, records over gloo: every rank returns the
+    unsharded h2v_verify_batch result — accepted batch, a proof rejected on another rank's shard, OS-drawn multipliers broadcast by
+    rank 0 (every rank must report the same accumulators), and a batch smaller than the world (empty shards)."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    ref = res[0][5]
+    for rank, good, rej, drawn, tiny, _ in res:
+        assert good == ref[0] and good[0] is True
+        assert rej == ref[1] and rej[0] is False and rej[1][30] == -5
+        assert tiny == ref[2] and tiny[0] is True
+        assert drawn[0] is True and drawn == res[0][3]
