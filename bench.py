@@ -35,13 +35,15 @@ K_CIRCUIT = 14
 N_PUBLIC = 8
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MAX_HW_QUEUES = 16      # see hw_queue_env()
+SHORT_RUN_S = 0.05      # a timed region shorter than this is repeated and its median reported (--repeats)
 
 
 def hw_queue_env():
     """A batch's tail (window Horner, pairing) is one or two waves; throughput comes from several launches in flight, each on
     its own HIP stream.  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), which would
-    serialise most of them; ask for 16 before the runtime initialises.  More is not better (24 measured slower) and the
-    runtime aborts at 32 on this stack, so an inherited larger value is clamped, not trusted."""
+    serialise most of them; ask for 16 before the runtime initialises.  More is not better (profiles/r02_hw_queues.txt: 24, 32 and
+    64 queues all run to completion at the same ~10 M proofs/s; round 1's "aborts at 32" was not reproducible), so an inherited
+    larger value is clamped to the measured setting rather than trusted."""
     try:
         v = int(os.environ.get("GPU_MAX_HW_QUEUES", MAX_HW_QUEUES))
     except ValueError:
@@ -74,6 +76,51 @@ def load_or_make_proofs(count, k, log):
         os.replace(p + ".tmp", p)
     log(f"generated {count} proofs (k={k}) with {threads} threads in {time.time() - t:.1f}s")
     return d
+
+
+def load_or_make_wide(count, k, log):
+    """BASELINE.json config 4: `count` distinct proofs of the lookup-heavy VK (32 advice, 16 fixed, 8 two-column lookups, gate degree
+    5: 74 points + 170 scalars = 7808-byte proofs, 124 right-channel terms), cached on disk.  k = 10 here: the test prover needs
+    ~70 s per proof at the k = 16 BASELINE.json names (that size is covered for parity by tests/golden/wide_k16_lookup_heavy.json);
+    the verifier's work per proof does not depend on k beyond the k squarings of x^n."""
+    import concurrent.futures
+    import circuits
+    cache = os.path.join(ROOT, ".bench_cache")
+    os.makedirs(cache, exist_ok=True)
+    tag = f"wide_k{k}_a32_f16_l8_d5_n{count}"
+    paths = {x: os.path.join(cache, f"{tag}.{x}") for x in ("proofs", "inst", "vk", "params")}
+    if all(os.path.exists(p) for p in paths.values()):
+        d = {x: open(p, "rb").read() for x, p in paths.items()}
+        if len(d["proofs"]) % count == 0 and len(d["inst"]) == count * 32 * 8:
+            return d
+    t = time.time()
+    s = circuits.setup_wide(k, A=32, F=16, L_=8, Sh=0, deg=5)
+    threads = min(32, os.cpu_count() or 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as ex:   # ctypes releases the GIL; the setup is read-only
+        pairs = list(ex.map(lambda i: circuits.prove_wide(s, witness_seed=i, rng_seed=1000 + i), range(count)))
+    d = dict(proofs=b"".join(p for p, _ in pairs), inst=b"".join(b"".join(col) for _, inst in pairs for col in inst), vk=s.vk, params=s.params)
+    s.free()
+    for x, p in paths.items():
+        with open(p + ".tmp", "wb") as f:
+            f.write(d[x])
+        os.replace(p + ".tmp", p)
+    log(f"generated {count} lookup-heavy proofs (k={k}) with {threads} threads in {time.time() - t:.1f}s")
+    return d
+
+
+def oracle_group(d, n, draws):
+    """(ok, left_xy, right_xy) of the CPU oracle for the first n bench proofs under the given draws (n x 32 bytes): the parity
+    reference for one timed group of the benchmark."""
+    import oracle_lib
+    L = oracle_lib.load()
+    cl = (ctypes.c_size_t * 1)(N_PUBLIC)
+    st = (ctypes.c_int * n)()
+    ok = ctypes.c_int(0)
+    left, right = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    rc = L.h2o_verify_batch(d["params"], len(d["params"]), 1, d["vk"], len(d["vk"]), 1, n, d["proofs"][: n * 1024], 1024, d["inst"][: n * 32 * N_PUBLIC], cl, 1, draws, st,
+                            ctypes.byref(ok), left, right)
+    assert rc == 0
+    return bool(ok.value), left.raw, right.raw
 
 
 def cpu_baseline(d, sample, log):
@@ -165,6 +212,94 @@ def traffic_record(terms_per_launch):
     return b * terms_per_launch / t, f"{rel} scaled per term ({t} -> {terms_per_launch} terms per launch; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes)", tj
 
 
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def config4_leg(h2v, args, log):
+    """BASELINE.json config 4 on one GPU: batches of 1024 lookup-heavy proofs, 8 batches per launch, 4 launches in flight, every
+    batch its own accumulators and pairing — the same pipeline as the headline on the VK that stresses expression evaluation."""
+    import torch
+    k, B, G, depth, launches = 10, 1024, 8, 4, 12
+    d = load_or_make_wide(B, k, log)
+    plen = len(d["proofs"]) // B
+    ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes))
+    shape = ctx.proof_shape()
+    tail = b"".join(((i * 0x9e3779b97f4a7c15 + 77) % (1 << 250)).to_bytes(32, "little") for i in range(1, B * G + 1))
+    bs = []
+    for _ in range(depth):
+        b = h2v.Batch(ctx, B * G, 8, groups=G)
+        b.upload(d["proofs"] * G, plen, d["inst"] * G, [8], tail)
+        bs.append(b)
+    fl = [False] * depth
+
+    def retire(i):
+        ok, st, _, _ = bs[i].finish_groups(raw_statuses=True)
+        fl[i] = False
+        if not all(ok) or st.count(0) != len(st):
+            raise SystemExit("verification failed inside the config-4 leg")
+
+    def run(n):
+        for k2 in range(n):
+            i = k2 % depth
+            if fl[i]:
+                retire(i)
+            bs[i].launch(True); fl[i] = True
+        for i in range(depth):
+            if fl[i]:
+                retire(i)
+    run(depth)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(launches); dt = time.perf_counter() - t0
+    # one batch alone (latency)
+    b1 = h2v.Batch(ctx, B, 8)
+    b1.upload(d["proofs"], plen, d["inst"], [8], tail[: 32 * B]); b1.set_profiling(True)
+    alone = []
+    for _ in range(5):
+        t1 = time.perf_counter(); b1.launch(True); ok1, st1, _, _ = b1.finish(); alone.append(time.perf_counter() - t1)
+        assert ok1
+    stages = b1.timings_ms()
+    b1.close()
+    for b in bs:
+        b.close()
+    ctx.close()
+    return {"workload": f"lookup-heavy VK (32 advice, 16 fixed, 8 two-column lookups, gate degree 5), k={k} (BASELINE.json names k=16: parity at that size by tests/golden/wide_k16_lookup_heavy.json; "
+                        f"the test prover needs ~70 s per k=16 proof), {B} distinct proofs of {plen} B ({shape['n_points']} points, {shape['n_scalars']} scalars, {shape['n_right_terms']} right-channel terms), "
+                        f"SHPLONK/Blake2b, batches of {B}, {G} batches per launch, {depth} launches in flight, {launches} launches timed",
+            "value": B * G * launches / dt, "unit": "proofs/s", "ms_per_batch": dt / (G * launches) * 1e3,
+            "one_batch_alone_ms": _median(alone) * 1e3, "one_batch_alone_stages_ms": stages}
+
+
+def single_strategy_leg(h2v, ctx, d, args):
+    """SingleStrategy on the GPU (one pairing per proof, kzg/strategy.rs:143-181): 512 one-proof groups per launch — what
+    h2v_verify_each runs — on the bench proofs, resident in HBM like the headline; and the one-shot call including packing and upload."""
+    n = 512
+    ones = b"".join((1).to_bytes(32, "little") for _ in range(n))
+    b = h2v.Batch(ctx, n, N_PUBLIC, groups=n)
+    b.upload(d["proofs"][: n * 1024], 1024, d["inst"][: n * 32 * N_PUBLIC], [N_PUBLIC], ones)
+    times = []
+    for i in range(9):
+        t0 = time.perf_counter()
+        b.launch(True)
+        ok, st, _, _ = b.finish_groups(raw_statuses=True)
+        times.append(time.perf_counter() - t0)
+        if not all(ok) or st.count(0) != len(st):
+            raise SystemExit("verification failed inside the SingleStrategy leg")
+    b.close()
+    P = [d["proofs"][i * 1024:(i + 1) * 1024] for i in range(n)]
+    I = [[[d["inst"][(i * N_PUBLIC + j) * 32:(i * N_PUBLIC + j + 1) * 32] for j in range(N_PUBLIC)]] for i in range(n)]
+    ctx.verify_each(P[:8], I[:8])
+    t0 = time.perf_counter(); st = ctx.verify_each(P, I); t_api = time.perf_counter() - t0
+    assert st == [0] * n
+    t0 = time.perf_counter(); st1 = ctx.verify_each(P[:1], I[:1]); t_one = time.perf_counter() - t0
+    assert st1 == [0]
+    dt = _median(times[2:])
+    return {"value": n / dt, "unit": "proofs/s", "sample": f"{n} proofs per launch as one-proof groups (own MSMs, own pairing each), resident in HBM, median of {len(times) - 2} launches, {dt * 1e3:.2f} ms per launch",
+            "one_shot_api": {"value": n / t_api, "unit": "proofs/s", "note": f"h2v_verify_each({n} proofs) from host byte strings: packing + upload + launch + results, {t_api * 1e3:.2f} ms"},
+            "one_proof_latency_ms": t_one * 1e3}
+
+
 def rank_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -237,7 +372,7 @@ def rank_main(args):
     ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes), device=local_rank)
     shape = ctx.proof_shape()
 
-    def measure(B, steps, warmup, groups, depth_arg, reupload=False, isolated_launches=0):
+    def measure(B, steps, warmup, groups, depth_arg, reupload=False, isolated_launches=0, repeats=1):
         """Time exactly `steps` steps of B proofs per GPU.  A step is one batch of B proofs per GPU with its own accumulators
         and its own pairing (AccumulatorStrategy).  One launch carries G steps side by side (a grouped batch); `depth` launches
         are in flight; a remainder launch completes --steps.  Returns a dict of timings."""
@@ -258,41 +393,37 @@ def rank_main(args):
         # objects 0 .. depth-1 carry G steps each; object `depth` (if any) carries the `rem` steps that complete --steps
         sizes = [G] * depth + ([rem] if rem else [])
         streams = [torch.cuda.Stream(device=local_rank) for _ in sizes]
-        batches = []
+        # the library's sharded-batch object (halo2_verifier_amd/distributed.py): at N = 1 a launch ends in its own pairings, at
+        # N > 1 it runs shard -> export -> RCCL all-gather of G x 1312 B per rank -> fold -> ONE pairing per step
+        shards, batches = [], []
         for s, g in zip(streams, sizes):
-            b = h2v.Batch(ctx, B * g, N_PUBLIC, stream=s.cuda_stream, groups=g)
-            b.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
-            b.set_profiling(h2v.Batch.PROFILE_KERNEL)   # timed region: only the dominant kernel's own timestamps (stage events are barrier packets)
-            batches.append(b)
-        acc_local = [torch.empty(h2d.ACC_BYTES * g, dtype=torch.uint8, device=dev) for g in sizes]
-        gathered = [None] * len(sizes)
+            sb = h2d.ShardedBatch(ctx, B * g, N_PUBLIC, groups=g, stream=s.cuda_stream, device=dev,
+                                  always_exchange=bool(os.environ.get("H2V_BENCH_FORCE_SHARDED")))   # (the knob runs the N > 1 call sequence on one GPU: what sharding costs besides the collective)
+            sb.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
+            sb.batch.set_profiling(h2v.Batch.PROFILE_KERNEL)   # timed region: only the dominant kernel's own timestamps (stage events are barrier packets)
+            shards.append(sb); batches.append(sb.batch)
         in_flight = [False] * len(sizes)
+        last_group0 = [None]
         stage_sum = {k: 0.0 for k in h2v.Batch.STAGES}
         stage_cnt = [0]
         uploads = [(proofs_one * g, inst_one * g, b"".join(tails[:g])) for g in sizes] if reupload else None
 
         def retire(i, timed):
-            ok, st, left, right = batches[i].finish_groups(raw_statuses=True)   # every proof's status, as the C array's bytes: all zero <=> all OK
+            ok, st, left, right = shards[i].finish(raw_statuses=True)   # every proof's status, as the C array's bytes: all zero <=> all OK
             in_flight[i] = False
             if not all(ok) or st.count(0) != len(st):
                 raise SystemExit(f"verification failed inside the benchmark: ok={ok}")
+            if timed and i == 0:
+                last_group0[0] = (left[0], right[0])   # accumulators of timed group 0: compared with the CPU oracle after the timed region
             if timed and i < depth:   # stage statistics are per full launch
                 for k2, v in batches[i].timings_ms().items():
                     stage_sum[k2] += v
                 stage_cnt[0] += 1
 
         def submit(i):
-            b = batches[i]
             if uploads:
-                b.upload(uploads[i][0], 1024, uploads[i][1], [N_PUBLIC], uploads[i][2])
-            if world == 1 and not os.environ.get("H2V_BENCH_FORCE_SHARDED"):   # (the knob runs the N > 1 call sequence on one GPU: what sharding costs besides the collective)
-                b.launch(with_pairing=True)
-            else:
-                with torch.cuda.stream(streams[i]):
-                    b.launch(with_pairing=False)
-                    b.export_accumulators(acc_local[i].data_ptr())
-                    gathered[i] = h2d.gather_accumulators(acc_local[i], world)   # RCCL all-gather of G x 1312 B per rank
-                    b.fold_check_enqueue(gathered[i].data_ptr(), world)          # per step: fold + the ONE pairing for the whole step
+                shards[i].upload(uploads[i][0], 1024, uploads[i][1], [N_PUBLIC], uploads[i][2])
+            shards[i].launch()
             in_flight[i] = True
 
         def run(n_launches, timed, with_rem):
@@ -307,20 +438,31 @@ def rank_main(args):
                 if in_flight[i]:
                     retire(i, timed)
 
+        def timed_region():
+            """EXACTLY `steps` steps between barrier + synchronize on both sides; the maximum over ranks."""
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(launches, True, True)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dt1], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt1 = float(tmax.item())
+            return dt1
+
         run(warm_launches, False, True)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(launches, True, True)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+        runs = [timed_region()]
+        # A timed region of a few milliseconds is ONE sample of a latency chain (the driver's `--steps 20` is a single 3 ms launch;
+        # between boxes of the pool it moved by +-4 %): such a region is repeated — the same K steps, the same launches — and the
+        # MEDIAN is what the line reports, with every run listed.  Every rank takes the same decision (the times are the max over ranks).
+        if repeats > 1 and runs[0] < SHORT_RUN_S:
+            runs += [timed_region() for _ in range(repeats - 1)]
+        dt = sorted(runs)[len(runs) // 2]
         stages = {k2: v / max(stage_cnt[0], 1) for k2, v in stage_sum.items()}
         # Outside the timed region: a few launches with ONE launch in flight, so that the HIP-event stage times are those of
         # the kernels alone (with several launches in flight a stage's elapsed time includes other streams' kernels).  The
@@ -335,21 +477,22 @@ def rank_main(args):
                 submit(0)
                 retire(0, True)
             isolated = {k2: v / max(stage_cnt[0], 1) for k2, v in stage_sum.items()}
-        for b in batches:
-            b.close()
+        for sb in shards:
+            sb.close()
         n_local = hi - lo
         n_shared = max(shape["n_right_terms"] - shape["n_points"], 0)
         # terms of one launch: every point slot of every local proof (right channel) + the VK-wide bases folded
         # over the batch (fixed + permutation commitments + g) + one h2 term per proof (left channel)
         terms_launch = G * (n_local * shape["n_points"] + n_shared + n_local)
-        return dict(dt=dt, G=G, launches=launches, rem=rem, depth=depth, total=total, stages=stages, isolated=isolated, terms_launch=terms_launch, B=B)
+        return dict(dt=dt, runs=runs, G=G, launches=launches, rem=rem, depth=depth, total=total, stages=stages, isolated=isolated, terms_launch=terms_launch, B=B,
+                    group0=last_group0[0], group0_draws=tails[0] if world == 1 else None)
 
-    m = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=args.reupload, isolated_launches=4 if world == 1 else 2)
+    m = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=args.reupload, isolated_launches=4 if world == 1 else 2, repeats=args.repeats)
     m_re = None
     if world == 1 and not args.reupload and not args.no_reupload_leg:
         # PCIe-inclusive leg (SURVEY.md §8d timing method): the same K steps with the host buffers copied to the device again
         # before every launch; reported as value_reupload beside `value`, never instead of it
-        m_re = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=True)
+        m_re = measure(args.batch, args.steps, args.warmup, args.groups, args.depth, reupload=True, repeats=args.repeats)
     m_c3 = None
     if world > 1 and not args.no_config3:
         # BASELINE.json configs 3 and 5: 8192 proofs per GPU per step (65 536 over 8 GPUs), ONE pairing for the whole N x 8192
@@ -384,6 +527,10 @@ def rank_main(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": m["dt"] / args.steps * 1e3,
+            "ms_per_step_runs": [r / args.steps * 1e3 for r in m["runs"]],
+            "timing_note": (f"the timed region ({args.steps} steps) is shorter than {SHORT_RUN_S * 1e3:.0f} ms, so it was run {len(m['runs'])} times (same steps, same launches, each between "
+                            "barrier + synchronize); value and ms_per_step are the MEDIAN run, ms_per_step_runs lists all of them in order") if len(m["runs"]) > 1
+                           else "one timed region of exactly --steps steps",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -415,6 +562,22 @@ def rank_main(args):
                                           f"{m_c3['G']} steps per launch, {m_c3['depth']} launches in flight, {args.config3_steps} steps timed",
                               "value": m_c3["total"] * args.config3_steps / m_c3["dt"], "unit": "proofs/s", "ms_per_step": m_c3["dt"] / args.config3_steps * 1e3,
                               "proofs_per_step": m_c3["total"]}
+        if world == 1 and not args.no_extra_legs:
+            out["config4"] = config4_leg(h2v, args, log)
+            out["single_strategy"] = single_strategy_leg(h2v, ctx, d, args)
+        if world == 1 and m["group0"] is not None and not args.no_cpu_baseline:
+            # parity of the benched launch itself: timed group 0 (the accumulators of its last timed launch) against the CPU oracle
+            # on the same proofs and the same draws — (left, right) bit for bit, both accepting
+            reps = (B + args.distinct - 1) // args.distinct
+            dd = {**d, "proofs": (d["proofs"] * reps)[: B * 1024], "inst": (d["inst"] * reps)[: B * 32 * N_PUBLIC]}
+            t0 = time.perf_counter()
+            ok_o, left_o, right_o = oracle_group(dd, B, m["group0_draws"][: 32 * B])
+            match = ok_o and (left_o, right_o) == m["group0"]
+            out["parity"] = {"checked": f"group 0 of the last timed launch ({B} proofs, its own draws): the (left, right) accumulator bytes of the GPU == the CPU oracle's, and both accept",
+                             "ok": bool(match), "oracle_s": time.perf_counter() - t0}
+            if not match:
+                print(json.dumps(out), file=sys.stderr, flush=True)
+                raise SystemExit("bench.py: the benched launch's accumulators differ from the CPU oracle's")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline({**d, "proofs": (d["proofs"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 1024],
                                                 "inst": (d["inst"] * ((args.cpu_sample + args.distinct - 1) // args.distinct))[: args.cpu_sample * 32 * N_PUBLIC]},
@@ -441,6 +604,8 @@ def main():
     ap.add_argument("--no-reupload-leg", action="store_true", help="skip the extra PCIe-inclusive leg (value_reupload)")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the extra 8192-proofs-per-GPU leg (BASELINE.json configs 3/5)")
     ap.add_argument("--config3-steps", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=7, help="a timed region shorter than 50 ms is run this many times and the median reported (1 = never repeat)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the config-4 (lookup-heavy VK) and SingleStrategy legs")
     ap.add_argument("--dry-run", action="store_true", help="print the launch plan (and, for N > 1, prove the N-rank rendezvous over gloo) without touching the GPU")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
