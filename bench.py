@@ -226,6 +226,8 @@ def config4_leg(h2v, args, log):
     plen = len(d["proofs"]) // B
     ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes))
     shape = ctx.proof_shape()
+    if args.tuning:   # measurement aid: forced kernel variants (h2v_ctx_set_tuning), e.g. --tuning msm_acc_waves=4
+        ctx.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
     tail = b"".join(((i * 0x9e3779b97f4a7c15 + 77) % (1 << 250)).to_bytes(32, "little") for i in range(1, B * G + 1))
     bs = []
     for _ in range(depth):
@@ -605,6 +607,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the extra 8192-proofs-per-GPU leg (BASELINE.json configs 3/5)")
     ap.add_argument("--config3-steps", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=7, help="a timed region shorter than 50 ms is run this many times and the median reported (1 = never repeat)")
+    ap.add_argument("--tuning", default="", help="measurement aid: forced kernel variants, key=value[,key=value...] of h2v_tuning (default: automatic)")
     ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the config-4 (lookup-heavy VK) and SingleStrategy legs")
     ap.add_argument("--dry-run", action="store_true", help="print the launch plan (and, for N > 1, prove the N-rank rendezvous over gloo) without touching the GPU")
     args = ap.parse_args()

@@ -36,7 +36,7 @@ template <class T> struct DevBuf {
 // the objects that choose (MsmWorkspace::tune, FrvmArgs, the pairing launcher's argument).  The library reads no environment variable.
 struct Tuning {
     int frvm_streams = 0, frvm_lds_kb = 0;
-    int msm_parts = 0, msm_global_sort = 0, msm_no_term_split = 0, msm_window_threads = 0, msm_window_wpw = 0, msm_window_slots = 0, msm_affine = 0;
+    int msm_parts = 0, msm_global_sort = 0, msm_no_term_split = 0, msm_window_threads = 0, msm_window_wpw = 0, msm_window_slots = 0, msm_acc_waves = 0;
     int pairing_one_stream = 0;
 };
 
@@ -108,6 +108,7 @@ struct MsmWorkspace {
     uint32_t cap_parents = 0;
     uint32_t* block_sums = nullptr;  // [cap_buckets / 1024 + 2] prefix-sum scratch
     G1JSlot* partial = nullptr;      // [2 * cap_list / chunk] head and tail pieces of the accumulation chunks
+    uint32_t* redo = nullptr;        // [cap_list / chunk] chunks msm_accumulate left to msm_accumulate_redo (complete formulas)
     uint32_t* glv = nullptr;         // [cap_list / 2] signed window digits of the launch's terms, window-major per problem (LDS sort path)
     G1A* phi_pts = nullptr;          // [cap_terms] phi(P) = (beta x, y) of every base of the launch (LDS sort path): made once per term instead of once per list entry
     uint32_t* seg_total = nullptr;   // [problems * windows] entries per list segment

@@ -47,28 +47,30 @@
 namespace h2v {
 
 // List entries per lane of msm_accumulate ("chunk"), chosen ON THE DEVICE from the number of entries E the sort produced: the
-// kernel holds 2 waves per SIMD (131072 lanes per round), and with a fixed chunk of 32 a 20-step launch (6.4 M entries) needed
-// 1.5 rounds — the second one half empty, i.e. the time of 64 additions per SIMD slot for 49 additions' worth of work.  The chunk
-// is the smallest length that fits E into a whole number of rounds (k rounds of at most 64 entries per lane), at least 16.
+// kernel holds 3 waves per SIMD (196608 lanes per round; 2 until round 3, see msm_accumulate), and with a fixed chunk of 32 a 20-step
+// launch (6.4 M entries) needed a second, mostly empty round.  The chunk is the smallest length that fits E into a whole number of
+// rounds (k rounds of at most 64 entries per lane), at least 16.
 #define MSM_LDS_SORT_MAX_TERMS 16384u
 #define MSM_SORT_THREADS 512u
 #define MSM_CHUNK_MIN 16u
 #define MSM_CHUNK_MAX 64u
-#define MSM_ACC_LANES_PER_ROUND 131072u
-__host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E) {
-    if (E <= MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MIN) return MSM_CHUNK_MIN;
-    const uint32_t k = (uint32_t)(((uint64_t)E + (uint64_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX - 1) / ((uint64_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX));
-    const uint32_t c = (uint32_t)(((uint64_t)E + (uint64_t)k * MSM_ACC_LANES_PER_ROUND - 1) / ((uint64_t)k * MSM_ACC_LANES_PER_ROUND));
+#define MSM_ACC_LANES_PER_ROUND 196608u   // 3 waves per SIMD x 1024 SIMDs x 64 lanes (msm_accumulate: 156 VGPRs since its slow path left the kernel)
+// (R = lanes per round: MSM_ACC_LANES_PER_ROUND, or 4 waves per SIMD's worth when the launch runs that variant — MsmSeg::lanes_round)
+__host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E, uint32_t R) {
+    if (E <= R * MSM_CHUNK_MIN) return MSM_CHUNK_MIN;
+    const uint32_t k = (uint32_t)(((uint64_t)E + (uint64_t)R * MSM_CHUNK_MAX - 1) / ((uint64_t)R * MSM_CHUNK_MAX));
+    const uint32_t c = (uint32_t)(((uint64_t)E + (uint64_t)k * R - 1) / ((uint64_t)k * R));
     return c < MSM_CHUNK_MIN ? MSM_CHUNK_MIN : c;
 }
 // workgroups of msm_accumulate for at most `max_entries` list entries: whatever E <= max_entries the device finds, its chunk
 // lanes ceil(E / msm_chunk_len(E)) stay within k whole rounds, k = the rounds of the bound itself
-static inline uint32_t msm_accumulate_blocks(size_t max_entries) {
+static inline uint32_t msm_accumulate_blocks(size_t max_entries, size_t R) {
     size_t lanes;
-    if (max_entries <= (size_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MIN) lanes = (max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
-    else lanes = (max_entries + (size_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX - 1) / ((size_t)MSM_ACC_LANES_PER_ROUND * MSM_CHUNK_MAX) * MSM_ACC_LANES_PER_ROUND;
+    if (max_entries <= R * MSM_CHUNK_MIN) lanes = (max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
+    else lanes = (max_entries + R * MSM_CHUNK_MAX - 1) / (R * MSM_CHUNK_MAX) * R;
     return (uint32_t)(((lanes + 63) / 64 + 1 + 7) / 8 * 8);
 }
+#define MSM_CONTROL_WORDS 8u     // counts[nb ..]: heavy buckets, E (list entries), straddling buckets, team buckets, chunks to redo
 #define MSM_FIXUP_SERIAL 64u     // a bucket spread over more chunks than this is summed by a workgroup
 #define MSM_FIXUP_TEAM 3u        // ... over more than this, by a team of eight lanes (the rest: one lane per bucket)
 #define MSM_FIXUP_TEAM_BLOCKS 256u
@@ -144,7 +146,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
         }
     }
     cap_buckets = mb;
-    H2V_HIP_CHECK(hipMalloc(&counts, (mb + 4) * 4));
+    H2V_HIP_CHECK(hipMalloc(&counts, (mb + MSM_CONTROL_WORDS) * 4));
     H2V_HIP_CHECK(hipMalloc(&offsets, mb * 4));
     H2V_HIP_CHECK(hipMalloc(&cursor, 2 * mb * 4));   // scatter cursors; then the fix-up's work lists (second half: the team list)
     H2V_HIP_CHECK(hipMalloc(&list, cap_list * 4));
@@ -156,6 +158,7 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&parents, (size_t)cap_parents * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
     H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&redo, (cap_list / MSM_CHUNK_MIN + 1) * 4));
     H2V_HIP_CHECK(hipMalloc(&glv, (cap_list / 2 + 1) * 4));   // digit table: one word per (term, window)
     H2V_HIP_CHECK(hipMalloc(&phi_pts, ((size_t)cap_terms + 1) * sizeof(G1A)));
     H2V_HIP_CHECK(hipMalloc(&seg_total, ((size_t)128 * cap_problems + 2) * 4));
@@ -178,6 +181,8 @@ void MsmWorkspace::release() {
     parents = nullptr; merged_sums = nullptr; final_problems = nullptr; cap_parents = 0;
     if (block_sums) hipFree(block_sums);
     if (partial) hipFree(partial);
+    if (redo) hipFree(redo);
+    redo = nullptr;
     if (glv) hipFree(glv);
     if (phi_pts) hipFree(phi_pts);
     phi_pts = nullptr;
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(1024) msm_seg_scan(const uint32_t* __restrict_
         if (t == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (t == 0) { seg_start[nseg] = carry; control[0] = 0; control[1] = carry; control[2] = 0; control[3] = 0; }
+    if (t == 0) { seg_start[nseg] = carry; control[0] = 0; control[1] = carry; control[2] = 0; control[3] = 0; control[4] = 0; }
 }
 
 // the base an entry refers to: P, -P, phi(P) or -phi(P), phi(x, y) = (beta * x, y) — split into the load and the fix-up so that
@@ -551,7 +556,7 @@ __global__ void __launch_bounds__(1024) msm_offsets(const uint32_t* __restrict__
 // list[s * stride + i], its first logical position is seg_start[s], and offsets[b] is the bin's start INSIDE its segment.  The LDS
 // sort writes one segment per (problem, window) (each workgroup writes its own contiguous piece, no global prefix sum before the
 // stores); the global counting sort is the one-segment case (bps = all bins, seg_start = {0, E}).
-struct MsmSeg { const uint32_t* seg_start; uint32_t nseg, bps, stride; };
+struct MsmSeg { const uint32_t* seg_start; uint32_t nseg, bps, stride, lanes_round; };
 __device__ __forceinline__ uint32_t msm_bin_start(const MsmSeg& g, const uint32_t* __restrict__ offsets, uint32_t b) { return g.seg_start[b / g.bps] + offsets[b]; }
 // the bin that holds logical position pos: the last bin whose start is <= pos (empty bins share the start of the next non-empty one)
 __device__ __forceinline__ uint32_t msm_bin_of(const MsmSeg& g, const uint32_t* __restrict__ offsets, uint32_t pos) {
@@ -572,7 +577,7 @@ __device__ __forceinline__ G1JSlot* msm_piece_dst(G1JSlot* __restrict__ bucket_p
 // complete (slow, call-based) group law for the rare chunk in which a point meets itself or its negative
 __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                             const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, uint32_t lane, uint32_t E, MsmSeg g) {
-    const uint32_t CH = msm_chunk_len(E);
+    const uint32_t CH = msm_chunk_len(E, g.lanes_round);
     const uint32_t chunk_lo = lane * CH, chunk_hi = min(chunk_lo + CH, E);
     uint32_t b = msm_bin_of(g, offsets, chunk_lo);
     uint32_t bin_lo = msm_bin_start(g, offsets, b), bin_hi = bin_lo + counts[b];
@@ -594,9 +599,23 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
         }
     }
 }
+// (b, bin_lo, bin_hi) is the chunk's last bucket.  If it goes on past the chunk and BEGINS here, this lane enters it in the fix-up's
+// work lists (`lists` = the scatter cursors, free by now): buckets that straddle chunks from the front (their number in control[2]),
+// buckets spread over >= MSM_FIXUP_SERIAL chunks from the back (control[0]), the ones in between in the second half (control[3]).  A
+// separate pass over all buckets to build the lists was 0.08 ms of a 20-step launch.
+__device__ __forceinline__ void msm_chunk_tail(uint32_t b, uint32_t bin_lo, uint32_t bin_hi, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t CH, uint32_t lane, uint32_t nb,
+                                               uint32_t* __restrict__ control, uint32_t* __restrict__ lists) {
+    if (bin_hi > chunk_hi && bin_lo >= chunk_lo) {
+        const uint32_t span = (bin_hi - 1) / CH - lane;   // further chunks the bucket runs into
+        if (span >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&control[0], 1u)] = b;
+        else if (span >= MSM_FIXUP_TEAM) lists[nb + atomicAdd(&control[3], 1u)] = b;   // summed by a team of lanes
+        else lists[atomicAdd(&control[2], 1u)] = b;
+    }
+}
 __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, const MsmSeg& g,
-                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const G1A* __restrict__ phi_pts, uint32_t E, uint32_t CH, uint32_t lane) {
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const G1A* __restrict__ phi_pts, uint32_t* __restrict__ redo, uint32_t E, uint32_t CH,
+                                                     uint32_t lane) {
     const uint32_t chunk_lo = lane * CH;
     if (chunk_lo >= E) return;
     const uint32_t chunk_hi = min(chunk_lo + CH, E);
@@ -639,34 +658,41 @@ __device__ __forceinline__ void msm_accumulate_chunk(const MsmProblem* __restric
         }
         b = b_next; bin_lo = lo_next; bin_hi = hi_next; qi = qn; q = q_next;
     }
-    if (!ok) {
-        msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E, g);  // redo the chunk with complete formulas
-        b = msm_bin_of(g, offsets, chunk_hi - 1); bin_lo = msm_bin_start(g, offsets, b); bin_hi = bin_lo + counts[b];
-    }
-    // (b, bin_lo, bin_hi) is the chunk's last bucket.  If it goes on past the chunk and BEGINS here, this lane enters it in the fix-up's
-    // work lists (`lists` = the scatter cursors, free by now): buckets that straddle chunks from the front (their number in control[2]),
-    // buckets spread over >= MSM_FIXUP_SERIAL chunks from the back (control[0]), the ones in between in the second half (control[3]).  A separate pass over all buckets to build the
-    // lists was 0.08 ms of a 20-step launch.
-    if (bin_hi > chunk_hi && bin_lo >= chunk_lo) {
-        const uint32_t span = (bin_hi - 1) / CH - lane;   // further chunks the bucket runs into
-        if (span >= MSM_FIXUP_SERIAL) lists[nb - 1 - atomicAdd(&control[0], 1u)] = b;
-        else if (span >= MSM_FIXUP_TEAM) lists[nb + atomicAdd(&control[3], 1u)] = b;   // summed by a team of lanes
-        else lists[atomicAdd(&control[2], 1u)] = b;
-    }
+    // A chunk in which a point met itself or its negative is NOT redone here: the complete formulas live behind calls, and a kernel
+    // is given the registers of its hungriest callee — with the slow path inside, this kernel was compiled for 252 VGPRs (two waves
+    // per SIMD) although its loop needs 156 (three).  The lane lists its chunk (control[4]) and msm_accumulate_redo, a small launch
+    // right behind this one, redoes the listed chunks with complete formulas (adversarial inputs only; the tests construct them).
+    if (!ok) { redo[atomicAdd(&control[4], 1u)] = lane; return; }
+    msm_chunk_tail(b, bin_lo, bin_hi, chunk_lo, chunk_hi, CH, lane, nb, control, lists);
 }
-__global__ void __launch_bounds__(64) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+// WPE = waves per SIMD the kernel is compiled for: 3 (156 registers, nothing spilled) is the default; 4 fits 128 registers with 30 of
+// them spilled to scratch (h2v_tuning.msm_acc_waves; measured in DESIGN.md)
+template <int WPE> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) msm_accumulate(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g,
-                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const G1A* __restrict__ phi_pts) {
+                                                     uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const G1A* __restrict__ phi_pts, uint32_t* __restrict__ redo) {
     const uint32_t E = counts[nb + 1];
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The list is sorted by (problem, window, bucket),
     // so giving XCD x the x-th eighth of the chunks keeps the bases an XCD gathers to one or two problems' points (~1 MB
     // each) instead of all of them (15 MB per 16-step launch): the gathers hit in L2 instead of going out to the fabric.
-    const uint32_t CH = msm_chunk_len(E);
+    const uint32_t CH = msm_chunk_len(E, g.lanes_round);
     const uint32_t blocks = ((E + CH - 1) / CH + 63) / 64, per_xcd = (blocks + 7) / 8;
     // The grid (a multiple of 8) covers the host's bound on the entry count (msm_accumulate_blocks); were there more entries than
     // promised (MsmProblem::nnz), a workgroup takes several blocks of chunks — slower, never wrong.
     for (uint32_t j = blockIdx.x / 8; j < per_xcd; j += gridDim.x / 8)
-        msm_accumulate_chunk(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, g, control, lists, phi_pts, E, CH, ((blockIdx.x % 8) * per_xcd + j) * 64 + threadIdx.x);
+        msm_accumulate_chunk(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, g, control, lists, phi_pts, redo, E, CH, ((blockIdx.x % 8) * per_xcd + j) * 64 + threadIdx.x);
+}
+// the chunks msm_accumulate gave up on (a point met itself or its negative inside a bucket), with the complete group law
+__global__ void __launch_bounds__(64) msm_accumulate_redo(const MsmProblem* __restrict__ prs, uint32_t nbq, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ list, G1JSlot* __restrict__ bucket_pts, G1JSlot* __restrict__ partial, uint32_t nb, MsmSeg g,
+                                                          uint32_t* __restrict__ control, uint32_t* __restrict__ lists, const uint32_t* __restrict__ redo) {
+    const uint32_t n_redo = control[4], E = counts[nb + 1], CH = msm_chunk_len(E, g.lanes_round);
+    // every lane reaches the exit condition: the list is complete before this kernel starts
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_redo; i += gridDim.x * blockDim.x) {
+        const uint32_t lane = redo[i], chunk_lo = lane * CH, chunk_hi = min(chunk_lo + CH, E);
+        msm_chunk_slow(prs, nbq, counts, offsets, list, bucket_pts, partial, nb, lane, E, g);
+        const uint32_t b = msm_bin_of(g, offsets, chunk_hi - 1), bin_lo = msm_bin_start(g, offsets, b), bin_hi = bin_lo + counts[b];
+        msm_chunk_tail(b, bin_lo, bin_hi, chunk_lo, chunk_hi, CH, lane, nb, control, lists);
+    }
 }
 
 // the piece of bucket [off, off + cnt) that chunk i holds: its tail piece when the bucket starts inside the chunk, else its head piece
@@ -686,7 +712,7 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
 __device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                             const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, const MsmSeg& g) {
     const uint32_t n_team = counts[nb + 3], r = threadIdx.x & 7u;
-    const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+    const uint32_t CH = msm_chunk_len(counts[nb + 1], g.lanes_round);
     // whole waves loop together (the shuffles below need all eight lanes of a team): the trip count is rounded up per wave
     for (uint32_t m0 = blockIdx.x * 8; m0 < n_team; m0 += MSM_FIXUP_TEAM_BLOCKS * 8) {
         const uint32_t m = m0 + (threadIdx.x >> 3);
@@ -714,7 +740,7 @@ __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ cou
     if (k >= counts[nb + 2]) return;
     const uint32_t b = lists[k];
     const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
-    const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+    const uint32_t CH = msm_chunk_len(counts[nb + 1], g.lanes_round);
     const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
     // in-register additions; pieces of one bucket can coincide or cancel (the same point in two chunks): complete formulas then
     G1J acc = msm_piece_src(partial, i0, i0, off, CH)->p;
@@ -732,7 +758,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint3
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const uint32_t b = heavy[nb - 1 - h];
         const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
-        const uint32_t CH = msm_chunk_len(counts[nb + 1]);
+        const uint32_t CH = msm_chunk_len(counts[nb + 1], g.lanes_round);
         const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
         G1J acc = G1J::identity();
         for (uint32_t i = i0 + t; i <= i1; i += MSM_HEAVY_THREADS) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off, CH));
@@ -1028,14 +1054,15 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     const bool lds_sort = nmax <= MSM_LDS_SORT_MAX_TERMS && sort_lds <= 150 * 1024 && (size_t)count * p.windows * stride <= ws.cap_list &&
                           (size_t)count * p.windows <= (size_t)128 * ws.cap_problems && !ws.tune.msm_global_sort;
     MsmSeg g;
+    const uint32_t lanes_round = ws.tune.msm_acc_waves == 4 ? 262144u : MSM_ACC_LANES_PER_ROUND;
     if (lds_sort) {
         hipLaunchKernelGGL(msm_glv_prep, dim3((nmax + 255) / 256, count), dim3(256), 0, s, ws.problems, count, p, ws.glv, ws.phi_pts);
         if (sort_lds > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
         hipLaunchKernelGGL(msm_sort_lds, dim3(p.windows, count), dim3(MSM_SORT_THREADS), sort_lds, s, ws.problems, ws.glv, p, stride, ws.counts, ws.offsets, ws.list, ws.seg_total);
         hipLaunchKernelGGL(msm_seg_scan, dim3(1), dim3(1024), 0, s, ws.seg_total, p.windows * count, ws.seg_start, ws.counts + nb);
-        g = MsmSeg{ws.seg_start, p.windows * count, p.buckets, stride};
+        g = MsmSeg{ws.seg_start, p.windows * count, p.buckets, stride, lanes_round};
     } else {
-    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + 4) * 4, s));
+    H2V_HIP_CHECK(hipMemsetAsync(ws.counts, 0, ((size_t)nb + MSM_CONTROL_WORDS) * 4, s));
     H2V_HIP_CHECK(hipMemsetAsync(ws.seg_start, 0, 4, s));   // one segment that starts at 0
     const uint32_t tiles = (nmax + MSM_TILE - 1) / MSM_TILE;
     dim3 gt(8 * ((count + 7) / 8) * tiles);
@@ -1047,19 +1074,24 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     hipLaunchKernelGGL(msm_scan_sums, dim3(1), dim3(1024), 0, s, ws.block_sums, nblk, ws.counts + nb + 1);
     hipLaunchKernelGGL(msm_offsets, dim3(nblk), dim3(1024), 0, s, ws.counts, ws.block_sums, ws.offsets, ws.cursor, nb);
     hipLaunchKernelGGL(msm_count_or_scatter<true>, gt, dim3(MSM_TILE_THREADS), lds, s, ws.problems, count, tiles, p, wpp, ws.counts, ws.offsets, ws.cursor, ws.list);
-    g = MsmSeg{ws.seg_start, 1, nb, 0};
+    g = MsmSeg{ws.seg_start, 1, nb, 0, lanes_round};
     }
     // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers the host's bound on it.
     // Surplus workgroups are not free: the kernel holds exactly its occupancy in working workgroups (2 waves per SIMD), so the
     // surplus is dispatched after they retire, ~7 ns each — the old bound (every term non-zero, shortest chunk) cost 9 500 empty
     // workgroups, 0.07 ms, at the end of every 20-step launch.
-    const uint32_t acc_blocks = msm_accumulate_blocks(total_nz * 2 * p.windows);
-    // (the profiling events are attached to the dispatch itself — its own start and stop timestamps — instead of being recorded around it:
-    // a recorded event is a barrier packet, ~6 us of idle stream on either side of the kernel)
-    if (ws.profile) {
-        hipExtLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.ev_acc[0], ws.ev_acc[1], 0, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, lds_sort ? (const G1A*)ws.phi_pts : (const G1A*)nullptr);
-        ws.profile_recorded = true;
-    } else hipLaunchKernelGGL(msm_accumulate, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, lds_sort ? (const G1A*)ws.phi_pts : (const G1A*)nullptr);
+    const uint32_t acc_blocks = msm_accumulate_blocks(total_nz * 2 * p.windows, lanes_round);
+    {
+        const G1A* phi_tab = lds_sort ? (const G1A*)ws.phi_pts : (const G1A*)nullptr;
+        auto kern = ws.tune.msm_acc_waves == 4 ? msm_accumulate<4> : msm_accumulate<3>;
+        // (the profiling events are attached to the dispatch itself — its own start and stop timestamps — instead of being recorded around it:
+        // a recorded event is a barrier packet, ~6 us of idle stream on either side of the kernel)
+        if (ws.profile) {
+            hipExtLaunchKernelGGL(kern, dim3(acc_blocks), dim3(64), 0, s, ws.ev_acc[0], ws.ev_acc[1], 0, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, phi_tab, ws.redo);
+            ws.profile_recorded = true;
+        } else hipLaunchKernelGGL(kern, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, phi_tab, ws.redo);
+    }
+    hipLaunchKernelGGL(msm_accumulate_redo, dim3(256), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, ws.redo);
     hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64 + MSM_FIXUP_TEAM_BLOCKS), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {

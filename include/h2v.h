@@ -109,12 +109,12 @@ int h2v_ctx_create_ex(const uint8_t* params, size_t params_len, int params_forma
  *   msm_window_threads  lanes per window reduction (64, 128, 256; automatic by bucket and window count)
  *   msm_window_wpw      windows per workgroup of the window reduction (1, 2, 4)
  *   msm_window_slots    3: the 20 KB form of the window reduction without the two-bit digit table (automatic: beyond 1024 windows)
- *   msm_affine          1: force / 2: forbid the batched-affine bucket accumulation (automatic: by entries per bucket)
+ *   msm_acc_waves       3 or 4: waves per SIMD msm_accumulate is compiled for (automatic: 3 — 156 registers, no spills)
  *   pairing_one_stream  1: the single-stream pairing table over split accumulators instead of the two-stream one */
 typedef struct h2v_tuning {
     size_t struct_size;
     int frvm_streams, frvm_lds_kb;
-    int msm_parts, msm_global_sort, msm_no_term_split, msm_window_threads, msm_window_wpw, msm_window_slots, msm_affine;
+    int msm_parts, msm_global_sort, msm_no_term_split, msm_window_threads, msm_window_wpw, msm_window_slots, msm_acc_waves;
     int pairing_one_stream;
 } h2v_tuning;
 int h2v_ctx_set_tuning(h2v_ctx* ctx, const h2v_tuning* tuning);
