@@ -3,6 +3,7 @@
 #include "../../include/h2v.h"
 #include "batch.h"
 #include <string.h>
+#include <map>
 #include <stdio.h>
 
 using namespace h2v;
@@ -88,9 +89,10 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }  // lib.rs:51-55
     std::vector<size_t> lens(col_lens, col_lens + ncols);
-    PlanDevice* pd = nullptr;
-    int rc = ctx_get_plan(ctx, lens, &pd, b->want_guard);
+    PlanPin pin(ctx);
+    int rc = pin.get(lens, b->want_guard);
     if (rc) return rc;
+    PlanDevice* pd = pin.pd;
     const Plan& pl = pd->host;
     if (proof_len < pl.proof_len) { set_last_error("h2v_batch_upload: proof_len is shorter than this VK's proof"); return H2V_ERR_BAD_ARGUMENT; }
     if (pl.n_instance_values && n && !instances_flat) { set_last_error("h2v_batch_upload: instances missing"); return H2V_ERR_BAD_ARGUMENT; }
@@ -98,7 +100,8 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     if (b->groups > 1 && (n % b->groups || (rand_tail && n_tail % b->groups))) { set_last_error("h2v_batch_upload: n and n_tail must be multiples of the group count"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_buffers(b, pd))) return rc;
-    b->plan = pd; b->n = (uint32_t)n; b->launched = false;
+    if (b->plan) ctx_put_plan(ctx, b->plan);   // the batch holds its plan from upload to the next upload (or its destruction)
+    b->plan = pin.take(); b->n = (uint32_t)n; b->launched = false;
     std::vector<uint8_t> os_rand;
     if (!rand_tail) { if ((rc = os_random_scalars(os_rand, n))) return rc; rand_tail = os_rand.data(); n_tail = n; }
     for (size_t i = 0; i < n_tail; ++i) if (!scalar_is_canonical(rand_tail + 32 * i)) { set_last_error("h2v_batch_upload: rand32 scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; }
@@ -337,10 +340,10 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
     if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
     std::lock_guard<std::mutex> lock(ctx->mu);   // one one-shot call per context at a time (it owns the context's scratch batch)
     std::vector<size_t> lens(col_lens, col_lens + ncols);
-    PlanDevice* pd = nullptr;
-    int rc = ctx_get_plan(ctx, lens, &pd);
+    PlanPin pin(ctx);
+    int rc = pin.get(lens);
     if (rc) return rc;
-    const Plan& pl = pd->host;
+    const Plan& pl = pin.pd->host;
     size_t per_inst = (size_t)pl.n_instance_values * 32;
     std::vector<uint8_t> flat, iflat;
     std::vector<int> forced;
@@ -398,9 +401,10 @@ int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points,
     if (!ctx || !ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     // the layout does not depend on instance lengths; compile (or fetch) the plan for empty columns of the right count
     std::vector<size_t> lens(ctx_total_instance_columns(ctx), 0);
-    PlanDevice* pd = nullptr;
-    int rc = ctx_get_plan(const_cast<h2v_ctx*>(ctx), lens, &pd);
+    PlanPin pin(const_cast<h2v_ctx*>(ctx));
+    int rc = pin.get(lens);
     if (rc) return rc;
+    PlanDevice* pd = pin.pd;
     if (proof_len) *proof_len = pd->host.proof_len;
     if (n_points) *n_points = pd->host.n_points;
     if (n_scalars) *n_scalars = pd->host.n_scalars;
@@ -430,6 +434,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->plan) { ctx_put_plan(b->ctx, b->plan); b->plan = nullptr; }
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->phi); hipFree(b->ycanon); hipFree(b->results); hipFree(b->words); hipFree(b->chal);
     hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc);
     hipFree(b->line_ws);
@@ -457,7 +462,8 @@ int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t
 int h2v_batch_set_groups(h2v_batch* b, size_t groups) {
     if (!b || !groups || groups > MSM_MAX_PROBLEMS / 2 || groups > b->max_proofs) { set_last_error("h2v_batch_set_groups: bad group count"); return H2V_ERR_BAD_ARGUMENT; }
     if (b->stream) hipStreamSynchronize(b->stream);
-    b->groups = (uint32_t)groups; b->launched = false; b->plan = nullptr;  // the next upload re-sizes the workspace
+    if (b->plan) { ctx_put_plan(b->ctx, b->plan); b->plan = nullptr; }
+    b->groups = (uint32_t)groups; b->launched = false;  // the next upload re-sizes the workspace
     return 0;
 }
 int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out_left_xy, uint8_t* out_right_xy, size_t n_groups) {
@@ -508,9 +514,8 @@ int h2v_batch_timings(h2v_batch* b, float* ms, int cap) {
     return k;
 }
 
-int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts, int* ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
-    if (!ctx || !device_accumulators || !n_parts || !ok) { set_last_error("h2v_fold_check: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// (the caller holds ctx->mu)
+static int fold_check_locked(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts, int* ok, uint8_t* out_left_xy, uint8_t* out_right_xy) {
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     DevBuf<G1J> acc; DevBuf<uint32_t> d_ok, d_ident, d_failed; DevBuf<uint8_t> d_out;   // freed on every return path
@@ -529,6 +534,11 @@ int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts
     if (out_right_xy) memcpy(out_right_xy, outb + 64, 64);
     return 0;
 }
+int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts, int* ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    if (!ctx || !device_accumulators || !n_parts || !ok) { set_last_error("h2v_fold_check: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return fold_check_locked(ctx, device_accumulators, n_parts, ok, out_left_xy, out_right_xy);
+}
 
 int h2v_verify_batch(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,
                      const size_t* col_lens, const uint8_t* rand32, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
@@ -540,6 +550,11 @@ int h2v_verify_batch(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const
 // folded into the single pairing.  The multiplier of proof i is the product of the draws of ALL later proofs in call order
 // (kzg/strategy.rs:129, msm.rs:173-176), whatever group they fall in: the suffix products are computed once over the whole
 // sequence and every group gathers its own.
+// The instance shapes of a call are chosen by whoever supplies the proofs, and every distinct shape costs a plan compilation
+// (O(program length^2) host work, ~10 device uploads) and a resize of the batch workspace: a call takes at most
+// H2V_MAX_SHAPES_PER_CALL distinct shapes (H2V_ERR_UNSUPPORTED beyond), the groups share ONE batch object, and the plans go
+// through the context's bounded cache (H2V_MAX_CACHED_PLANS, least recently used out).
+#define H2V_MAX_SHAPES_PER_CALL 64
 int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32,
                             size_t n_instance_columns, const size_t* col_lens_per_proof, const uint8_t* rand32, int* per_proof_status, int* batch_ok,
                             uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
@@ -548,11 +563,16 @@ int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs
     if (n_instance_columns != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }
     const size_t nc = n_instance_columns;
     std::vector<std::pair<std::vector<size_t>, std::vector<size_t>>> groups;   // (shape, proof indices) in first-appearance order
+    std::map<std::vector<size_t>, size_t> group_of;
     for (size_t i = 0; i < n; ++i) {
         std::vector<size_t> shape(col_lens_per_proof + i * nc, col_lens_per_proof + (i + 1) * nc);
-        bool found = false;
-        for (auto& g : groups) if (g.first == shape) { g.second.push_back(i); found = true; break; }
-        if (!found) groups.push_back({shape, {i}});
+        auto it = group_of.find(shape);
+        if (it == group_of.end()) {
+            if (groups.size() == H2V_MAX_SHAPES_PER_CALL) { set_last_error("h2v_verify_batch_shapes: more than 64 distinct instance shapes in one call"); return H2V_ERR_UNSUPPORTED; }
+            it = group_of.emplace(shape, groups.size()).first;
+            groups.push_back({shape, {}});
+        }
+        groups[it->second].second.push_back(i);
     }
     if (groups.size() <= 1)
         return h2v_verify_batch(ctx, n, proofs, proof_lens, instances32, nc, n ? col_lens_per_proof : nullptr, rand32, per_proof_status, batch_ok, out_left_xy, out_right_xy);
@@ -560,44 +580,45 @@ int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs
     int rc;
     if (!rand32) { if ((rc = os_random_scalars(os_rand, n))) return rc; rand32 = os_rand.data(); }
     for (size_t i = 0; i < n; ++i) if (!scalar_is_canonical(rand32 + 32 * i)) { set_last_error("h2v_verify_batch_shapes: rand32 scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; }
+    std::lock_guard<std::mutex> lock(ctx->mu);   // a one-shot entry point: it owns the context's stream and scratch batch for its duration
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     // whole-sequence multipliers on the context's stream
     DevBuf<uint8_t> d_rand; DevBuf<Fr> d_mult; DevBuf<uint8_t> d_records; DevBuf<uint32_t> d_idx;
     if ((rc = d_rand.alloc(32 * n)) || (rc = d_mult.alloc(n)) || (rc = d_records.alloc(H2V_ACC_RECORD_BYTES * groups.size())) || (rc = d_idx.alloc(n))) return rc;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        H2V_HIP_CHECK(hipMemcpyAsync(d_rand.p, rand32, 32 * n, hipMemcpyHostToDevice, ctx->stream));
-        if ((rc = multipliers_enqueue(ctx->stream, d_rand.p, (uint32_t)n, (uint32_t)n, 1, d_mult.p))) return rc;
-        H2V_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    }
+    H2V_HIP_CHECK(hipMemcpyAsync(d_rand.p, rand32, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = multipliers_enqueue(ctx->stream, d_rand.p, (uint32_t)n, (uint32_t)n, 1, d_mult.p))) return rc;
+    H2V_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // one batch object serves every shape group (its workspace follows the group's plan: ensure_buffers)
+    size_t max_group = 1, max_inst = 0;
+    for (auto& g : groups) { max_group = std::max(max_group, g.second.size()); size_t t = 0; for (size_t l : g.first) t += l; max_inst = std::max(max_inst, t); }
+    h2v_batch* b = nullptr;
+    if ((rc = scratch_batch_take(ctx, max_group, max_inst, &b))) return rc;
+    b->want_guard = false;
     bool all_ok = true;
     size_t idx_off = 0;
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
+    for (size_t gi = 0; gi < groups.size() && !rc; ++gi) {
         const std::vector<size_t>& idx = groups[gi].second;
         const size_t m = idx.size();
-        PlanDevice* pd = nullptr;
-        if ((rc = ctx_get_plan(ctx, groups[gi].first, &pd))) return rc;
-        const Plan& pl = pd->host;
+        PlanPin pin(ctx);
+        if ((rc = pin.get(groups[gi].first))) break;
+        const Plan& pl = pin.pd->host;
         std::vector<const uint8_t*> pp(m), ip(m); std::vector<size_t> plen(m);
         for (size_t j = 0; j < m; ++j) { pp[j] = proofs[idx[j]]; plen[j] = proof_lens[idx[j]]; ip[j] = instances32 ? instances32[idx[j]] : nullptr; }
         std::vector<uint8_t> flat, iflat; std::vector<int> forced;
-        if ((rc = pack_inputs(pl, m, pp.data(), plen.data(), ip.data(), flat, iflat, forced))) return rc;
+        if ((rc = pack_inputs(pl, m, pp.data(), plen.data(), ip.data(), flat, iflat, forced))) break;
         std::vector<uint32_t> idx32(idx.begin(), idx.end());
-        H2V_HIP_CHECK(hipMemcpy(d_idx.p + idx_off, idx32.data(), 4 * m, hipMemcpyHostToDevice));
-        h2v_batch* b = nullptr;
-        if ((rc = h2v_batch_create(ctx, m, pl.n_instance_values, &b))) return rc;
+        if (hipMemcpy(d_idx.p + idx_off, idx32.data(), 4 * m, hipMemcpyHostToDevice) != hipSuccess) { set_last_error("h2v_verify_batch_shapes: hipMemcpy failed"); rc = H2V_ERR_DEVICE; break; }
         std::vector<uint8_t> ones(32 * m, 0);
         for (size_t j = 0; j < m; ++j) ones[32 * j] = 1;      // placeholder draws: the multipliers come from d_mult
         std::vector<int> st(m, 0); int gok = 0;
-        do {
-            if ((rc = upload_impl(b, m, flat.data(), pl.proof_len, iflat.data(), nc, groups[gi].first.data(), ones.data(), m))) break;
-            b->ext_mult = d_mult.p; b->ext_idx = d_idx.p + idx_off;
-            if ((rc = launch_impl(b, 0))) break;
-            if ((rc = export_batch_records(b, d_records.p + gi * H2V_ACC_RECORD_BYTES))) break;
-            if ((rc = finish_impl(b, st.data(), &gok, nullptr, nullptr))) break;
-        } while (0);
-        h2v_batch_destroy(b);
-        if (rc) return rc;
+        if ((rc = h2v_batch_set_groups(b, 1))) break;
+        if ((rc = upload_impl(b, m, flat.data(), pl.proof_len, iflat.data(), nc, groups[gi].first.data(), ones.data(), m))) break;
+        b->ext_mult = d_mult.p; b->ext_idx = d_idx.p + idx_off;
+        rc = launch_impl(b, 0);
+        if (!rc) rc = export_batch_records(b, d_records.p + gi * H2V_ACC_RECORD_BYTES);
+        if (!rc) rc = finish_impl(b, st.data(), &gok, nullptr, nullptr);
+        b->ext_mult = nullptr; b->ext_idx = nullptr;
+        if (rc) break;
         for (size_t j = 0; j < m; ++j) {
             int v = forced[j] ? forced[j] : st[j];
             if (per_proof_status) per_proof_status[idx[j]] = v;
@@ -605,8 +626,10 @@ int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs
         }
         idx_off += m;
     }
+    if (rc) { h2v_batch_destroy(b); return rc; }
+    scratch_batch_give(ctx, b);
     int ok = 0;
-    if ((rc = h2v_fold_check(ctx, d_records.p, groups.size(), &ok, out_left_xy, out_right_xy))) return rc;
+    if ((rc = fold_check_locked(ctx, d_records.p, groups.size(), &ok, out_left_xy, out_right_xy))) return rc;
     if (batch_ok) *batch_ok = (ok && all_ok) ? 1 : 0;
     return 0;
 }

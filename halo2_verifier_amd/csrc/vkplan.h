@@ -129,15 +129,35 @@ struct PlanDevice {
     uint32_t* point_offsets = nullptr;
     uint32_t* scalar_offsets = nullptr;
     G1A* shared_bases = nullptr; G1A* shared_phi = nullptr;   // the VK-wide bases and their images under phi (MsmProblem::phi2)
+    int pins = 0;             // users that hold the plan (batches between upload and their next upload / destruction, entry points while
+                              // they read it); guarded by VkDevice::mu.  Only unpinned plans are evicted.
+    uint64_t last_use = 0;    // VkDevice::clock at the last ctx_get_plan
     int upload();
     void release();
 };
 
+// Compiled plans of one VK, keyed by instance column lengths.  A plan costs a compilation (one single-stream emit + three list
+// schedules, O(n^2) in the program length) and ~10 device allocations, and callers choose the key — the instance shapes of
+// UNTRUSTED proofs (h2v_verify_batch_shapes) — so the cache is bounded: beyond H2V_MAX_CACHED_PLANS the least recently used plan
+// that nobody holds is released.
+#define H2V_MAX_CACHED_PLANS 32
 struct VkDevice {
     VkHost vk;
-    std::map<std::vector<size_t>, PlanDevice*> plans;  // keyed by instance column lengths
+    std::map<std::vector<size_t>, PlanDevice*> plans;
+    uint64_t clock = 0;
     std::mutex mu;
 };
+// The plan comes back PINNED: every successful ctx_get_plan is paired with one ctx_put_plan (PlanPin does it for a scope).
 int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens, PlanDevice** out, bool guard_terms = false);
+void ctx_put_plan(h2v_ctx* ctx, PlanDevice* pd);
+struct PlanPin {
+    h2v_ctx* ctx; PlanDevice* pd = nullptr;
+    explicit PlanPin(h2v_ctx* c) : ctx(c) {}
+    PlanPin(const PlanPin&) = delete;
+    PlanPin& operator=(const PlanPin&) = delete;
+    ~PlanPin() { if (pd) ctx_put_plan(ctx, pd); }
+    int get(const std::vector<size_t>& col_lens, bool guard_terms = false) { if (pd) { ctx_put_plan(ctx, pd); pd = nullptr; } return ctx_get_plan(ctx, col_lens, &pd, guard_terms); }
+    PlanDevice* take() { PlanDevice* p = pd; pd = nullptr; return p; }   // the pin moves to the caller
+};
 
 }  // namespace h2v

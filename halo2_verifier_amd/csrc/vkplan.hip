@@ -1146,8 +1146,9 @@ int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens_in, PlanDevic
     std::vector<size_t> key = col_lens_in;
     if (guard_terms) key.push_back((size_t)-1);
     const std::vector<size_t>& col_lens = col_lens_in;
-    auto it = ctx->vk->plans.find(key);
-    if (it != ctx->vk->plans.end()) { *out = it->second; return 0; }
+    VkDevice& vd = *ctx->vk;
+    auto it = vd.plans.find(key);
+    if (it != vd.plans.end()) { it->second->last_use = ++vd.clock; ++it->second->pins; *out = it->second; return 0; }
     PlanDevice* pd = new PlanDevice();
     std::string err;
     PlanOptions po; po.multiopen = ctx->multiopen; po.transcript = ctx->transcript; po.circuit_instances = ctx->circuit_instances; po.guard_terms = guard_terms; po.instance_kernel_threshold = ctx->instance_kernel_threshold;
@@ -1156,9 +1157,24 @@ int ctx_get_plan(h2v_ctx* ctx, const std::vector<size_t>& col_lens_in, PlanDevic
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     rc = pd->upload();
     if (rc) { pd->release(); delete pd; return rc; }
-    ctx->vk->plans[key] = pd;
+    pd->last_use = ++vd.clock; pd->pins = 1;
+    vd.plans[key] = pd;
+    // bounded cache: release the least recently used plans nobody holds (never the one just made: it is pinned)
+    while (vd.plans.size() > H2V_MAX_CACHED_PLANS) {
+        auto victim = vd.plans.end();
+        for (auto jt = vd.plans.begin(); jt != vd.plans.end(); ++jt)
+            if (jt->second->pins == 0 && (victim == vd.plans.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+        if (victim == vd.plans.end()) break;   // everything is in use: the cache may exceed its bound while that lasts
+        victim->second->release(); delete victim->second;
+        vd.plans.erase(victim);
+    }
     *out = pd;
     return 0;
+}
+void ctx_put_plan(h2v_ctx* ctx, PlanDevice* pd) {
+    if (!pd || !ctx->vk) return;
+    std::lock_guard<std::mutex> lock(ctx->vk->mu);
+    if (pd->pins > 0) --pd->pins;
 }
 
 }  // namespace h2v

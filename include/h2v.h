@@ -159,7 +159,11 @@ int h2v_verify_batch(h2v_ctx* ctx, size_t n,
  * verify_proof allow (`instances: &[&[&[Fr]]]` is an argument of each call, lib.rs:33-49).  col_lens_per_proof is
  * [n][n_instance_columns]; instances32[i] is the concatenation of proof i's columns.  Proofs are grouped by shape inside the
  * library (one compiled plan per shape); the multipliers follow call order over the whole batch and ONE pairing closes it, so
- * the result equals n calls of verify_proof on one AccumulatorStrategy followed by finalize(). */
+ * the result equals n calls of verify_proof on one AccumulatorStrategy followed by finalize().
+ * Cost and limits: every distinct shape compiles a plan (host work quadratic in the per-proof program's length, ~10 device uploads)
+ * and resizes the workspace, and the shapes are chosen by whoever supplies the proofs — so one call takes at most 64 distinct
+ * shapes (H2V_ERR_UNSUPPORTED beyond) and a context keeps at most 32 compiled plans (least recently used out; plans held by a
+ * batch object stay). */
 int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n,
                             const uint8_t* const* proofs, const size_t* proof_lens,
                             const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens_per_proof,

@@ -89,3 +89,36 @@ def test_one_strategy_accumulates_proofs_of_different_vks():
         strat = h2v.verify_proof(params, vks[id(s)], strat, i, p)
     assert circuits.oracle_accumulate(bad, rand)[0] is False and strat.finalize() is False
     s8.free(); s4.free()
+
+
+def test_many_instance_shapes_go_through_a_bounded_plan_cache():
+    """Instance shapes are chosen by whoever supplies the proofs, and every distinct shape compiles a plan: the
+    context keeps at most 32 plans (least recently used out; a plan held by a batch stays), one call takes at most 64 distinct shapes.
+    40 shapes in one accumulation — more than the cache holds — still give the oracle's result, a second pass over the same shapes
+    (every plan recompiled or re-fetched) gives it again, and 65 shapes in one call are refused with H2V_ERR_UNSUPPORTED."""
+    import halo2_verifier_amd as h2v
+    s = circuits.setup_vector_mul(8, 70)
+    lens = list(range(1, 41))
+    P, I = _mixed(s, lens, 21)
+    rnd = random.Random(210)
+    rand = [rnd.randrange(1, R_MOD) for _ in P]
+    ctx = _ctx(s)
+    exp = circuits.oracle_accumulate([(s, p, i) for p, i in zip(P, I)], rand)
+    assert exp[0] is True
+    assert ctx.verify_batch(P, I, rand) == exp
+    assert ctx.verify_batch(list(reversed(P)), list(reversed(I)), list(reversed(rand)))[0] is True
+    assert ctx.verify_batch(P, I, rand) == exp
+    # a staged batch holds its plan while 40 other shapes pass through the cache
+    b = h2v.Batch(ctx, 1, 70)
+    flat = b"".join(I[6][0])
+    b.upload(P[6], len(P[6]), flat, [len(I[6][0])], rand[6].to_bytes(32, "little"))
+    assert ctx.verify_batch(P, I, rand) == exp
+    b.launch(with_pairing=True)
+    assert b.finish()[0] is True
+    b.close()
+    P65, I65 = _mixed(s, list(range(0, 65)), 22)
+    with pytest.raises(h2v.H2VError) as e:
+        ctx.verify_batch(P65, I65, [1] * 65)
+    assert e.value.code == -19
+    ctx.close()
+    s.free()
