@@ -34,13 +34,18 @@ SIGNATURES = {
     "h2v_ctx_destroy": (None, [c_vp]),
     "h2v_abi_version": (c_int, []),
     "h2v_ctx_set_tuning": (c_int, [c_vp, ctypes.c_void_p]),
+    "h2v_vk_convert": (c_int, [c_u8p, c_sz, c_int, c_int, c_int, c_u8p, c_szp]),
+    "h2v_params_convert": (c_int, [c_u8p, c_sz, c_int, c_int, c_u8p, c_szp]),
     "h2v_ctx_proof_shape": (c_int, [c_vp, c_szp, c_szp, c_szp, c_szp, c_szp]),
     "h2v_msm_g1": (c_int, [c_vp, c_u8p, c_u8p, c_sz, c_u8p, c_intp]),
     "h2v_pairing_check": (c_int, [c_vp, c_u8p, c_u8p, c_intp]),
     "h2v_verify_batch": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_u8p, c_intp, c_intp, c_u8p, c_u8p]),
     "h2v_verify_batch_shapes": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_u8p, c_intp, c_intp, c_u8p, c_u8p]),
+    "h2v_verify_batch_seeded": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_u8p, c_u8p, c_u8p, c_sz, c_u8p, c_u8p, c_sz,
+                                        c_intp, c_intp, c_u8p, c_u8p]),
     "h2v_verify_each": (c_int, [c_vp, c_sz, ctypes.POINTER(c_u8p), c_szp, ctypes.POINTER(c_u8p), c_sz, c_szp, c_intp]),
     "h2v_guard_msm": (c_int, [c_vp, c_u8p, c_sz, c_u8p, c_sz, c_szp, c_u8p, c_u8p, c_szp, c_u8p, c_u8p, c_szp, c_u8p, c_szp]),
+    "h2v_random_scalars": (c_int, [c_u8p, c_sz]),
     "h2v_batch_create": (c_int, [c_vp, c_sz, c_sz, ctypes.POINTER(c_vp)]),
     "h2v_batch_destroy": (None, [c_vp]),
     "h2v_batch_upload": (c_int, [c_vp, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_szp, c_u8p, c_sz]),

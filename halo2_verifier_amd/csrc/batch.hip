@@ -397,6 +397,15 @@ int pack_and_run(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const siz
 
 extern "C" {
 
+int h2v_random_scalars(uint8_t* out32, size_t n) {
+    if (n && !out32) { set_last_error("h2v_random_scalars: null argument"); return H2V_ERR_BAD_ARGUMENT; }
+    std::vector<uint8_t> v;
+    int rc = os_random_scalars(v, n);
+    if (rc) return rc;
+    if (n) memcpy(out32, v.data(), 32 * n);
+    return 0;
+}
+
 int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points, size_t* n_scalars, size_t* n_right_terms, size_t* n_instance_columns) {
     if (!ctx || !ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     // the layout does not depend on instance lengths; compile (or fetch) the plan for empty columns of the right count
@@ -543,6 +552,66 @@ int h2v_fold_check(h2v_ctx* ctx, const void* device_accumulators, size_t n_parts
 int h2v_verify_batch(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,
                      const size_t* col_lens, const uint8_t* rand32, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
     return pack_and_run(ctx, n, proofs, proof_lens, instances32, n_instance_columns, col_lens, rand32, false, 1, per_proof_status, batch_ok, out_left_xy, out_right_xy, nullptr);
+}
+
+// AccumulatorStrategy::with(msm_accumulator) (kzg/strategy.rs:75-78): the strategy starts from an existing DualMSM — the
+// reference's only pause / resume hook — instead of an empty one.  Every later process() scales the WHOLE accumulator by its fresh
+// draw before the proof's Guard joins (strategy.rs:129), so the seed ends up scaled by the product of ALL n draws of this call:
+// the seed's two channels are evaluated (two pooled MSMs with the scalars already multiplied by that product), written as a
+// record, and folded with the batch's own record into the one pairing.
+int h2v_verify_batch_seeded(h2v_ctx* ctx, size_t n, const uint8_t* const* proofs, const size_t* proof_lens, const uint8_t* const* instances32, size_t n_instance_columns,
+                            const size_t* col_lens, const uint8_t* rand32,
+                            const uint8_t* seed_left_scalars32, const uint8_t* seed_left_bases64, size_t n_seed_left,
+                            const uint8_t* seed_right_scalars32, const uint8_t* seed_right_bases64, size_t n_seed_right,
+                            int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
+    if (!ctx || (n_seed_left && (!seed_left_scalars32 || !seed_left_bases64)) || (n_seed_right && (!seed_right_scalars32 || !seed_right_bases64))) {
+        set_last_error("h2v_verify_batch_seeded: null argument"); return H2V_ERR_BAD_ARGUMENT;
+    }
+    if (n_seed_left > (1u << 24) || n_seed_right > (1u << 24)) { set_last_error("h2v_verify_batch_seeded: seed too large"); return H2V_ERR_BAD_ARGUMENT; }
+    int rc;
+    std::vector<uint8_t> os_rand;
+    if (!rand32 && n) { if ((rc = os_random_scalars(os_rand, n))) return rc; rand32 = os_rand.data(); }
+    // the product of this call's draws, and the seed's scalars times it (host: a few hundred Fr products)
+    Fr M = Fr::one();
+    for (size_t i = 0; i < n; ++i) { Fr r; if (!Fr::from_bytes(rand32 + 32 * i, r)) { set_last_error("h2v_verify_batch_seeded: rand32 scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; } M = M * r; }
+    std::vector<uint8_t> sc[2];
+    const uint8_t* in_s[2] = {seed_left_scalars32, seed_right_scalars32};
+    const size_t ns[2] = {n_seed_left, n_seed_right};
+    for (int side = 0; side < 2; ++side) {
+        sc[side].resize(32 * ns[side]);
+        for (size_t j = 0; j < ns[side]; ++j) {
+            Fr v;
+            if (!Fr::from_bytes(in_s[side] + 32 * j, v)) { set_last_error("h2v_verify_batch_seeded: seed scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; }
+            (v * M).to_bytes(&sc[side][32 * j]);
+        }
+    }
+    uint8_t seed_xy[128];
+    int ident = 0;
+    if ((rc = h2v_msm_g1(ctx, sc[0].data(), seed_left_bases64, n_seed_left, seed_xy, &ident))) return rc;         // (rejects bases that are not on the curve)
+    if ((rc = h2v_msm_g1(ctx, sc[1].data(), seed_right_bases64, n_seed_right, seed_xy + 64, &ident))) return rc;
+    // the proofs: one batch without its pairing, kept for the fold
+    h2v_batch* b = nullptr;
+    int ok_unused = 0;
+    if ((rc = pack_and_run(ctx, n, proofs, proof_lens, instances32, n_instance_columns, col_lens, rand32, false, 0, per_proof_status, &ok_unused, nullptr, nullptr, &b))) return rc;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    do {
+        if (hipSetDevice(ctx->device) != hipSuccess) { rc = H2V_ERR_DEVICE; break; }
+        DevBuf<uint8_t> d_xy, d_records; DevBuf<G1A> d_aff; DevBuf<G1J> d_jac; DevBuf<uint32_t> d_flags;
+        if ((rc = d_xy.alloc(128)) || (rc = d_records.alloc(2 * H2V_ACC_RECORD_BYTES)) || (rc = d_aff.alloc(2)) || (rc = d_jac.alloc(2)) || (rc = d_flags.alloc(2))) break;
+        hipStream_t s = b->stream;
+        if (hipMemcpyAsync(d_xy.p, seed_xy, 128, hipMemcpyHostToDevice, s) != hipSuccess) { set_last_error("h2v_verify_batch_seeded: copy failed"); rc = H2V_ERR_DEVICE; break; }
+        if ((rc = bases_from_bytes_enqueue(s, d_xy.p, d_aff.p, d_flags.p, 2))) break;
+        if ((rc = affine_to_jacobian_enqueue(s, d_aff.p, d_jac.p, 2))) break;
+        if ((rc = export_batch_records(b, d_records.p))) break;                                                                  // record 0: the proofs of this call
+        if ((rc = export_records_enqueue(s, d_jac.p, nullptr, 1, 0, nullptr, 0, 1, d_records.p + H2V_ACC_RECORD_BYTES))) break;   // record 1: the scaled seed
+        if ((rc = h2v_batch_fold_check_enqueue(b, d_records.p, 2))) break;
+        int ok = 0;
+        if ((rc = finish_impl(b, nullptr, &ok, out_left_xy, out_right_xy))) break;   // (synchronises: the scoped buffers outlive their use)
+        if (per_proof_status) for (size_t i = 0; i < n; ++i) if (per_proof_status[i] != 0) ok = 0;   // (short proofs: statuses forced on the host)
+        if (batch_ok) *batch_ok = ok;
+    } while (0);
+    if (rc) h2v_batch_destroy(b); else scratch_batch_give(ctx, b);
+    return rc;
 }
 
 // N x verify_proof with per-proof instance shapes (lib.rs:33-49 takes `instances` per call): proofs are grouped by shape

@@ -37,10 +37,14 @@ struct VkHost {
     std::vector<LookupH> lookups;
     std::vector<ShuffleH> shuffles;
     std::vector<Fr> coeff_vals;
+    std::vector<uint8_t> selector_bytes;   // the selector bitmaps as read (num_selectors x ceil(2^k / 8) bytes): unused by verification, kept for VerifyingKey::write
     size_t blinding_factors() const;  // plonk/vk.rs:396-401
 };
 // VerifyingKey::read (plonk/vk.rs:76-115, 274-365); false + message when the bytes are rejected
 bool vk_from_bytes(const uint8_t* data, size_t len, int format, VkHost& out, std::string& err);
+// VerifyingKey::write (plonk/vk.rs:41-64); layout: H2V_VK_LAYOUT_WRITER / _READER (serde.hip)
+void vk_to_bytes(const VkHost& vk, int format, int layout, std::vector<uint8_t>& out);
+void params_to_bytes(const ParamsHost& p, int format, std::vector<uint8_t>& out);
 
 // ---------------------------------------------------------------- Fr program
 enum VmOp : uint32_t {

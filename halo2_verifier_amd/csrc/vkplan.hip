@@ -126,7 +126,8 @@ bool vk_from_bytes(const uint8_t* data, size_t len, int fmt, VkHost& vk, std::st
     vk.permutation_commitments.resize(vk.permutation_columns.size());
     for (auto& c : vk.permutation_commitments) if (!read_g1(r, fmt, c, err)) return false;
     size_t sel_bytes = (((size_t)1 << vk.k) + 7) / 8;
-    for (uint32_t i = 0; i < vk.num_selectors; ++i) r.take(sel_bytes);  // selector bitmaps: unused by verification
+    if ((size_t)vk.num_selectors * sel_bytes > len) { err = "failed to fill whole buffer"; return false; }
+    for (uint32_t i = 0; i < vk.num_selectors; ++i) { const uint8_t* sb = r.take(sel_bytes); if (r.ok) vk.selector_bytes.insert(vk.selector_bytes.end(), sb, sb + sel_bytes); }  // selector bitmaps: unused by verification
     if (!read_fr(r, fmt, vk.transcript_repr, err)) return false;
     if (!r.ok) { err = "failed to fill whole buffer"; return false; }
     if (vk.cs_degree < 3) { err = "cs_degree below the permutation argument's minimum of 3"; return false; }

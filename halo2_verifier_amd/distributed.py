@@ -61,7 +61,14 @@ def tail_for_shard(rand_all: bytes, lo: int):
 def draw_scalars(n: int) -> bytes:
     """n x Fr::random(OsRng) as AccumulatorStrategy::process draws them (kzg/strategy.rs:129): 64 OS-random bytes reduced mod r,
     32 little-endian canonical bytes each."""
-    return b"".join((int.from_bytes(os.urandom(64), "little") % _FR_MODULUS).to_bytes(32, "little") for _ in range(n))
+    try:   # the library's own generator (h2v_random_scalars: what rand32 = NULL draws inside the one-shot entry points)
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(max(32 * n, 1))
+        _lib.check(_lib.load_library().h2v_random_scalars(buf, n))
+        return buf.raw[: 32 * n]
+    except _lib.H2VError:   # library not built (orchestration tests without the product): the same distribution from os.urandom
+        return b"".join((int.from_bytes(os.urandom(64), "little") % _FR_MODULUS).to_bytes(32, "little") for _ in range(n))
 
 
 def _scalar_bytes(rand) -> bytes:

@@ -74,6 +74,18 @@ class ParamsKZG:
     def k(self):
         return int.from_bytes(self.data[:4], "little")
 
+    def to_bytes(self, fmt: SerdeFormat = SerdeFormat.Processed) -> bytes:
+        """ParamsKZG::write_custom / to_bytes in another SerdeFormat (kzg/commitment.rs:142-152, 215-224; to_bytes = Processed)."""
+        lib = _lib.load_library()
+        n = ctypes.c_size_t(0)
+        check(lib.h2v_params_convert(self.data, len(self.data), int(self.format), int(fmt), None, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        check(lib.h2v_params_convert(self.data, len(self.data), int(self.format), int(fmt), buf, ctypes.byref(n)))
+        return buf.raw[: n.value]
+
+    def write(self, fmt: SerdeFormat = SerdeFormat.RawBytes) -> bytes:
+        return self.to_bytes(fmt)
+
 
 class VerifyingKey:
     """VerifyingKey bytes in the reference's format (plonk/vk.rs:41-115)."""
@@ -87,6 +99,21 @@ class VerifyingKey:
         return cls(data, fmt)
 
     from_bytes = read
+
+    LAYOUT_WRITER, LAYOUT_READER = 0, 1
+
+    def to_bytes(self, fmt: SerdeFormat, layout: int = 0) -> bytes:
+        """VerifyingKey::write / to_bytes (plonk/vk.rs:41-64, 118-123) in `fmt`.  layout: LAYOUT_WRITER = exactly what the reference's
+        writer emits; LAYOUT_READER = what its reader consumes — they differ for lookup / shuffle arguments of more than one
+        expression pair (include/h2v.h, h2v_vk_convert)."""
+        lib = _lib.load_library()
+        n = ctypes.c_size_t(0)
+        check(lib.h2v_vk_convert(self.data, len(self.data), int(self.format), int(fmt), int(layout), None, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        check(lib.h2v_vk_convert(self.data, len(self.data), int(self.format), int(fmt), int(layout), buf, ctypes.byref(n)))
+        return buf.raw[: n.value]
+
+    write = to_bytes
 
 
 def _scalar32(v) -> bytes:
@@ -212,9 +239,11 @@ class Context:
         return dict(zip(keys, (v.value for v in vals)))
 
     # -- N x verify_proof + AccumulatorStrategy::finalize
-    def verify_batch(self, proofs, instances, rand=None):
+    def verify_batch(self, proofs, instances, rand=None, seed=None):
         """proofs: list of bytes; instances: per proof, list of columns of scalars (column lengths may differ from proof to
         proof, as N independent verify_proof calls allow); rand: list of n ints/bytes or None.
+        seed: an existing accumulator to start from — AccumulatorStrategy::with (kzg/strategy.rs:75-78) — as
+        ((left_scalars, left_bases), (right_scalars, right_bases)): scalars ints / 32-byte strings, bases 64-byte x | y.
         Returns (batch_ok, statuses, left_xy, right_xy)."""
         n, pa, pl, ia, shapes, ncols, _keep = _marshal_batch(self, proofs, instances)
         rb = None
@@ -226,7 +255,22 @@ class Context:
         ok = ctypes.c_int(0)
         left = ctypes.create_string_buffer(64)
         right = ctypes.create_string_buffer(64)
-        if all(l == shapes[0] for l in shapes):
+        if seed is not None:
+            if not all(l == shapes[0] for l in shapes):
+                raise ValueError("a seeded batch takes one instance shape")
+            sides = []
+            for scalars, bases in seed:
+                scalars, bases = list(scalars), list(bases)
+                if len(scalars) != len(bases):
+                    raise ValueError("seed scalars and bases differ in length")   # MSMKZG keeps them parallel (msm.rs:17-24)
+                if any(len(b) != 64 for b in bases):
+                    raise ValueError("every seed base must be 64 bytes (x | y)")
+                sides.append((b"".join(_scalar32(x) for x in scalars), b"".join(bases), len(scalars)))
+            lens = shapes[0] if shapes else [0] * ncols
+            cl = (ctypes.c_size_t * max(ncols, 1))(*lens)
+            check(self._lib.h2v_verify_batch_seeded(self._h, n, pa, pl, ia, ncols, cl, rb, sides[0][0], sides[0][1], sides[0][2], sides[1][0], sides[1][1], sides[1][2],
+                                                    st, ctypes.byref(ok), left, right))
+        elif all(l == shapes[0] for l in shapes):
             lens = shapes[0] if shapes else [0] * ncols
             cl = (ctypes.c_size_t * max(ncols, 1))(*lens)
             check(self._lib.h2v_verify_batch(self._h, n, pa, pl, ia, ncols, cl, rb, st, ctypes.byref(ok), left, right))
@@ -281,6 +325,17 @@ class AccumulatorStrategy(_Strategy):
     def __init__(self, params, rand=None, device=0, circuit_instances=1):
         super().__init__(params)
         self.rand, self.device, self.circuit_instances = rand, device, circuit_instances
+        self.seed = None
+        self.left_xy = self.right_xy = None   # the evaluated channels after finalize() (single-VK accumulations)
+
+    @classmethod
+    def with_accumulator(cls, params, left, right, rand=None, device=0, circuit_instances=1):
+        """AccumulatorStrategy::with(msm_accumulator) (kzg/strategy.rs:75-78): start from an existing DualMSM — left / right are
+        (scalars, bases) term lists as MSMKZG holds them.  A finished accumulation is resumed with left = ([1], [left_xy]),
+        right = ([1], [right_xy])."""
+        s = cls(params, rand=rand, device=device, circuit_instances=circuit_instances)
+        s.seed = (left, right)
+        return s
 
     def finalize(self) -> bool:
         """One pairing for everything that was accumulated.  verify_proof takes a VK per call and one strategy may accumulate
@@ -300,10 +355,12 @@ class AccumulatorStrategy(_Strategy):
         if len(groups) == 1:
             ctx = Context(self.params, self._items[0][0], self.device, circuit_instances=self.circuit_instances)
             try:
-                ok, _, _, _ = ctx.verify_batch([p for _, _, p in self._items], [i for _, i, _ in self._items], rand)
+                ok, _, self.left_xy, self.right_xy = ctx.verify_batch([p for _, _, p in self._items], [i for _, i, _ in self._items], rand, seed=self.seed)
                 return ok
             finally:
                 ctx.close()
+        if self.seed is not None:
+            raise ValueError("a seeded accumulation takes proofs of one VerifyingKey")
         return self._finalize_mixed(groups, rand)
 
     def _finalize_mixed(self, groups, rand):

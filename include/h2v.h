@@ -120,6 +120,20 @@ typedef struct h2v_tuning {
 int h2v_ctx_set_tuning(h2v_ctx* ctx, const h2v_tuning* tuning);
 void h2v_ctx_destroy(h2v_ctx* ctx);
 
+/* Re-serialisation of a VerifyingKey / ParamsKZG in another SerdeFormat — host only, no device needed:
+ *   replaces: VerifyingKey::read(from_format) followed by VerifyingKey::write / to_bytes(to_format)   (plonk/vk.rs:41-123)
+ *             ParamsKZG::read_custom followed by write_custom / to_bytes                               (poly/kzg/commitment.rs:142-224)
+ * out == NULL: *out_len receives the size.  Otherwise *out_len holds the capacity on entry and the size on return.
+ * layout (VerifyingKey only): the reference's writer emits a lookup / shuffle argument as all first expressions, then all second
+ * ones (lookup.rs:36-49, shuffle.rs:70-84), while its reader takes them in pairs (lookup.rs:51-68, shuffle.rs:86-102).  They
+ * agree for arguments of one expression pair; for more, the reference's read does not invert its write.
+ *   H2V_VK_LAYOUT_WRITER: exactly the bytes VerifyingKey::write produces;
+ *   H2V_VK_LAYOUT_READER: the bytes that VerifyingKey::read (and h2v_ctx_create) read back as the SAME key. */
+#define H2V_VK_LAYOUT_WRITER 0
+#define H2V_VK_LAYOUT_READER 1
+int h2v_vk_convert(const uint8_t* vk, size_t vk_len, int from_format, int to_format, int layout, uint8_t* out, size_t* out_len);
+int h2v_params_convert(const uint8_t* params, size_t params_len, int from_format, int to_format, uint8_t* out, size_t* out_len);
+
 /* Shape of one proof for this VK (Np points, Ns scalars, T_R right-channel terms). */
 int h2v_ctx_proof_shape(const h2v_ctx* ctx, size_t* proof_len, size_t* n_points, size_t* n_scalars,
                         size_t* n_right_terms, size_t* n_instance_columns);
@@ -171,6 +185,25 @@ int h2v_verify_batch_shapes(h2v_ctx* ctx, size_t n,
                             int* per_proof_status, int* batch_ok,
                             uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
 
+/* As h2v_verify_batch, starting from an existing accumulator instead of an empty one:
+ *   replaces: AccumulatorStrategy::with(msm_accumulator) (poly/kzg/strategy.rs:75-78) — the reference's only pause / resume hook —
+ *             followed by the same loop of verify_proof calls and finalize().
+ * The seed is a DualMSM as the reference holds it: two lists of (scalar, base) terms, left and right channel (either may be empty).
+ * Every verify_proof of this call scales the whole accumulator by its fresh draw before its Guard joins (strategy.rs:129), so the
+ * seed's terms end up multiplied by the product of all n draws — which is what makes
+ *     verify_batch(first half) -> (L, R);  verify_batch_seeded(second half, seed = {(1, L)}, {(1, R)})
+ * equal, bit for bit, to ONE verify_batch over both halves with the draws concatenated.
+ * Seed scalars: 32-byte canonical; seed bases: 64-byte x | y (all-zero = identity), rejected with H2V_ERR_BAD_ARGUMENT when not
+ * on the curve.  out_left_xy / out_right_xy: the evaluated channels of the final DualMSM, seed included. */
+int h2v_verify_batch_seeded(h2v_ctx* ctx, size_t n,
+                            const uint8_t* const* proofs, const size_t* proof_lens,
+                            const uint8_t* const* instances32, size_t n_instance_columns, const size_t* col_lens,
+                            const uint8_t* rand32,
+                            const uint8_t* seed_left_scalars32, const uint8_t* seed_left_bases64, size_t n_seed_left,
+                            const uint8_t* seed_right_scalars32, const uint8_t* seed_right_bases64, size_t n_seed_right,
+                            int* per_proof_status, int* batch_ok,
+                            uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
+
 /* N x verify_proof under SingleStrategy (one pairing per proof; poly/kzg/strategy.rs:164-176).
  * per_proof_status[i] = 0, or H2V_ERR_CONSTRAINT_SYSTEM_FAILURE when that proof's pairing fails,
  * or the transcript/opening error. */
@@ -189,6 +222,11 @@ int h2v_guard_msm(h2v_ctx* ctx, const uint8_t* proof, size_t proof_len,
                   uint8_t* right_scalars32, uint8_t* right_bases64, size_t* n_right,
                   uint8_t* left_scalars32, uint8_t* left_bases64, size_t* n_left,
                   uint8_t* challenges32, size_t* n_challenges);
+
+/* n x Fr::random(OsRng) as AccumulatorStrategy::process draws them (kzg/strategy.rs:129): 64 bytes of OS randomness reduced mod r,
+ * 32 canonical bytes each.  What rand32 = NULL makes the entry points above draw internally; a SHARDED batch needs the one stream
+ * on every rank (draw on one rank, broadcast, pass each rank its tail: h2v_batch_upload). */
+int h2v_random_scalars(uint8_t* out32, size_t n);
 
 /* ---- staged interface: inputs resident in HBM, asynchronous execution on the batch's stream.
  * h2v_verify_batch == upload + launch + finish.  A sharded (multi-GPU) run uses

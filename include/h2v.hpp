@@ -113,6 +113,18 @@ public:
     explicit AccumulatorStrategy(const ParamsKZG& p, int device = 0, MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b,
                                  int circuit_instances = 1)
         : params_(p), device_(device), mo_(mo), tr_(tr), ci_(circuit_instances) {}
+    // AccumulatorStrategy::with(msm_accumulator) (kzg/strategy.rs:75-78): start from an existing DualMSM; the channels are term lists
+    // as MSMKZG holds them — scalars 32 bytes each, bases 64 bytes (x | y) each.  A finished accumulation resumes with scalar 1 and
+    // its evaluated channels (left(), right()) as the single base of either side.
+    static AccumulatorStrategy with(const ParamsKZG& p, Bytes left_scalars, Bytes left_bases, Bytes right_scalars, Bytes right_bases, int device = 0,
+                                    MultiOpen mo = MultiOpen::SHPLONK, TranscriptKind tr = TranscriptKind::Blake2b, int circuit_instances = 1) {
+        if (left_scalars.size() % 32 || left_bases.size() != 2 * left_scalars.size() || right_scalars.size() % 32 || right_bases.size() != 2 * right_scalars.size())
+            throw Failure(H2V_ERR_BAD_ARGUMENT, "a seed channel is n 32-byte scalars and n 64-byte bases");
+        AccumulatorStrategy s(p, device, mo, tr, circuit_instances);
+        s.seeded_ = true;
+        s.seed_ls_ = std::move(left_scalars); s.seed_lb_ = std::move(left_bases); s.seed_rs_ = std::move(right_scalars); s.seed_rb_ = std::move(right_bases);
+        return s;
+    }
     // rand32: the Fr::random draws of process() (kzg/strategy.rs:129), one 32-byte canonical scalar per proof; empty = OS RNG
     void set_randomness(Bytes rand32) { rand_ = std::move(rand32); }
     void push(const VerifyingKey& vk, Instances inst, Bytes proof) {
@@ -129,7 +141,12 @@ public:
         statuses_.assign(items_.size() ? items_.size() : 1, 0);
         int ok = 0;
         if (!rand_.empty() && rand_.size() != 32 * items_.size()) throw Failure(H2V_ERR_BAD_ARGUMENT, "one 32-byte draw per proof");
-        if (pk.uniform)
+        if (seeded_) {
+            if (!pk.uniform) throw Failure(H2V_ERR_UNSUPPORTED, "a seeded accumulation takes one instance shape");
+            check(h2v_verify_batch_seeded(ctx.handle(), items_.size(), pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens.data(),
+                                          rand_.empty() ? nullptr : rand_.data(), seed_ls_.data(), seed_lb_.data(), seed_ls_.size() / 32, seed_rs_.data(), seed_rb_.data(),
+                                          seed_rs_.size() / 32, statuses_.data(), &ok, left_, right_));
+        } else if (pk.uniform)
             check(h2v_verify_batch(ctx.handle(), items_.size(), pk.proofs.data(), pk.lens.data(), pk.insts.data(), pk.col_lens.size(), pk.col_lens.data(),
                                    rand_.empty() ? nullptr : rand_.data(), statuses_.data(), &ok, left_, right_));
         else
@@ -146,6 +163,8 @@ private:
     ParamsKZG params_; VerifyingKey vk_; int device_; MultiOpen mo_; TranscriptKind tr_; int ci_;
     std::vector<std::pair<Instances, Bytes>> items_;
     Bytes rand_;
+    bool seeded_ = false;
+    Bytes seed_ls_, seed_lb_, seed_rs_, seed_rb_;
     std::vector<int> statuses_;
     uint8_t left_[64] = {0}, right_[64] = {0};
 };

@@ -16,6 +16,8 @@ use core::ffi::{c_char, c_float, c_int, c_void};
                                    pub msm_no_term_split: c_int, pub msm_window_threads: c_int, pub msm_window_wpw: c_int, pub msm_window_slots: c_int,
                                    pub msm_acc_waves: c_int, pub pairing_one_stream: c_int }
 pub const H2V_ABI_VERSION: c_int = 3;
+pub const H2V_VK_LAYOUT_WRITER: c_int = 0;
+pub const H2V_VK_LAYOUT_READER: c_int = 1;
 
 pub const H2V_OK: c_int = 0;
 pub const H2V_ERR_INVALID_INSTANCES: c_int = -1;
@@ -54,6 +56,8 @@ extern "C" {
     pub fn h2v_ctx_destroy(ctx: *mut h2v_ctx);
     pub fn h2v_abi_version() -> c_int;
     pub fn h2v_ctx_set_tuning(ctx: *mut h2v_ctx, tuning: *const h2v_tuning) -> c_int;
+    pub fn h2v_vk_convert(vk: *const u8, vk_len: usize, from_format: c_int, to_format: c_int, layout: c_int, out: *mut u8, out_len: *mut usize) -> c_int;
+    pub fn h2v_params_convert(params: *const u8, params_len: usize, from_format: c_int, to_format: c_int, out: *mut u8, out_len: *mut usize) -> c_int;
     pub fn h2v_ctx_proof_shape(ctx: *const h2v_ctx, proof_len: *mut usize, n_points: *mut usize, n_scalars: *mut usize,
                                n_right_terms: *mut usize, n_instance_columns: *mut usize) -> c_int;
     pub fn h2v_msm_g1(ctx: *mut h2v_ctx, scalars32: *const u8, bases64: *const u8, n: usize, out_xy: *mut u8, out_is_identity: *mut c_int) -> c_int;
@@ -64,12 +68,18 @@ extern "C" {
     pub fn h2v_verify_batch_shapes(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
                                    instances32: *const *const u8, n_instance_columns: usize, col_lens_per_proof: *const usize, rand32: *const u8,
                                    per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
+    pub fn h2v_verify_batch_seeded(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
+                                   instances32: *const *const u8, n_instance_columns: usize, col_lens: *const usize, rand32: *const u8,
+                                   seed_left_scalars32: *const u8, seed_left_bases64: *const u8, n_seed_left: usize,
+                                   seed_right_scalars32: *const u8, seed_right_bases64: *const u8, n_seed_right: usize,
+                                   per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
     pub fn h2v_verify_each(ctx: *mut h2v_ctx, n: usize, proofs: *const *const u8, proof_lens: *const usize,
                            instances32: *const *const u8, n_instance_columns: usize, col_lens: *const usize, per_proof_status: *mut c_int) -> c_int;
     pub fn h2v_guard_msm(ctx: *mut h2v_ctx, proof: *const u8, proof_len: usize, instances32: *const u8, n_instance_columns: usize, col_lens: *const usize,
                          right_scalars32: *mut u8, right_bases64: *mut u8, n_right: *mut usize,
                          left_scalars32: *mut u8, left_bases64: *mut u8, n_left: *mut usize,
                          challenges32: *mut u8, n_challenges: *mut usize) -> c_int;
+    pub fn h2v_random_scalars(out32: *mut u8, n: usize) -> c_int;
     pub fn h2v_batch_create(ctx: *mut h2v_ctx, max_proofs: usize, max_instance_values_per_proof: usize, out: *mut *mut h2v_batch) -> c_int;
     pub fn h2v_batch_destroy(b: *mut h2v_batch);
     pub fn h2v_batch_upload(b: *mut h2v_batch, n: usize, proofs_flat: *const u8, proof_len: usize, instances_flat: *const u8,
