@@ -50,6 +50,7 @@ SIGNATURES = {
     "h2v_batch_destroy": (None, [c_vp]),
     "h2v_batch_upload": (c_int, [c_vp, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_szp, c_u8p, c_sz]),
     "h2v_batch_launch": (c_int, [c_vp, c_int]),
+    "h2v_batch_upload_launch": (c_int, [c_vp, c_sz, c_u8p, c_sz, c_u8p, c_sz, c_szp, c_u8p, c_sz, c_int]),
     "h2v_batch_finish": (c_int, [c_vp, c_intp, c_intp, c_u8p, c_u8p]),
     "h2v_batch_set_groups": (c_int, [c_vp, c_sz]),
     "h2v_batch_finish_groups": (c_int, [c_vp, c_intp, c_intp, c_u8p, c_u8p, c_sz]),

@@ -72,6 +72,11 @@ struct StageArgs {
 };
 
 int decompress_stage_enqueue(hipStream_t s, const StageArgs& g);
+// the same stage in pieces (h2v_batch_upload_launch): reset the status words; decompress the points of proofs [p0, p1); check the
+// scalars of all proofs
+int decompress_begin_enqueue(hipStream_t s, const StageArgs& g);
+int decompress_range_enqueue(hipStream_t s, const StageArgs& g, uint32_t p0, uint32_t p1);
+int decompress_finish_enqueue(hipStream_t s, const StageArgs& g);
 int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
 // groups > 1: group g owns proofs [g*n/groups, ..) and the draws tail[g*n_tail/groups, ..)
 int multipliers_enqueue(hipStream_t s, const uint8_t* d_tail, uint32_t n_tail, uint32_t n, uint32_t groups, Fr* d_mult);
@@ -81,12 +86,18 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal);
 }  // namespace h2v
 
+#define H2V_UPLOAD_CHUNKS 8
 struct h2v_batch {
     h2v_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     hipStream_t aux = nullptr;        // the accumulators' affine conversion runs here, beside the pairing (both only read them)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
+    // h2v_batch_upload_launch: the host -> device copies run on `copy`, chunk by chunk, an event behind each; the decompression of a
+    // chunk waits for its event only, so it overlaps the copy of the next chunk
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_chunk[H2V_UPLOAD_CHUNKS + 1] = {nullptr};
+    bool decompressed = false;        // the next launch finds its points already decompressed (set by h2v_batch_upload_launch)
     size_t max_proofs = 0, max_inst = 0;
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)
     uint32_t n = 0, n_tail = 0;

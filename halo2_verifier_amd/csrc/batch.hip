@@ -81,8 +81,10 @@ int os_random_scalars(std::vector<uint8_t>& out, size_t n) {
     return 0;
 }
 
+// `overlap`: the copies run on the batch's copy stream in chunks and the decompression of every chunk is enqueued on the batch's own
+// stream behind that chunk's event (h2v_batch_upload_launch); otherwise everything is copied on the batch's stream (h2v_batch_upload).
 int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len, const uint8_t* instances_flat, size_t ncols, const size_t* col_lens,
-                const uint8_t* rand_tail, size_t n_tail) {
+                const uint8_t* rand_tail, size_t n_tail, bool overlap = false) {
     if (!b || (n && !proofs_flat)) { set_last_error("h2v_batch_upload: null argument"); return H2V_ERR_BAD_ARGUMENT; }
     if (n > b->max_proofs) { set_last_error("h2v_batch_upload: n exceeds the batch capacity"); return H2V_ERR_BAD_ARGUMENT; }
     h2v_ctx* ctx = b->ctx;
@@ -101,23 +103,61 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     H2V_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_buffers(b, pd))) return rc;
     if (b->plan) ctx_put_plan(ctx, b->plan);   // the batch holds its plan from upload to the next upload (or its destruction)
-    b->plan = pin.take(); b->n = (uint32_t)n; b->launched = false;
+    b->plan = pin.take(); b->n = (uint32_t)n; b->launched = false; b->decompressed = false;
     std::vector<uint8_t> os_rand;
     if (!rand_tail) { if ((rc = os_random_scalars(os_rand, n))) return rc; rand_tail = os_rand.data(); n_tail = n; }
     for (size_t i = 0; i < n_tail; ++i) if (!scalar_is_canonical(rand_tail + 32 * i)) { set_last_error("h2v_batch_upload: rand32 scalar not canonical"); return H2V_ERR_BAD_ARGUMENT; }
     if (n_tail > b->cap_tail) { if ((rc = dev_alloc(b->tail, 32 * n_tail))) return rc; b->cap_tail = n_tail; }
     b->n_tail = (uint32_t)n_tail;
     hipStream_t s = b->stream;
-    if (n) {
-        if (proof_len == pl.proof_len) H2V_HIP_CHECK(hipMemcpyAsync(b->proofs, proofs_flat, n * proof_len, hipMemcpyHostToDevice, s));
-        else H2V_HIP_CHECK(hipMemcpy2DAsync(b->proofs, pl.proof_len, proofs_flat, proof_len, pl.proof_len, n, hipMemcpyHostToDevice, s));
-        if (pl.n_instance_values) H2V_HIP_CHECK(hipMemcpyAsync(b->inst, instances_flat, n * (size_t)pl.n_instance_values * 32, hipMemcpyHostToDevice, s));
-        H2V_HIP_CHECK(hipMemcpyAsync(b->tail, rand_tail, 32 * n_tail, hipMemcpyHostToDevice, s));
+    if (!n) { H2V_HIP_CHECK(hipStreamSynchronize(s)); return 0; }
+    auto copy_proofs = [&](hipStream_t cs, size_t p0, size_t p1) -> int {
+        if (proof_len == pl.proof_len) H2V_HIP_CHECK(hipMemcpyAsync(b->proofs + p0 * pl.proof_len, proofs_flat + p0 * proof_len, (p1 - p0) * proof_len, hipMemcpyHostToDevice, cs));
+        else H2V_HIP_CHECK(hipMemcpy2DAsync(b->proofs + p0 * pl.proof_len, pl.proof_len, proofs_flat + p0 * proof_len, proof_len, pl.proof_len, p1 - p0, hipMemcpyHostToDevice, cs));
+        return 0;
+    };
+    auto copy_rest = [&](hipStream_t cs) -> int {
+        if (pl.n_instance_values) H2V_HIP_CHECK(hipMemcpyAsync(b->inst, instances_flat, n * (size_t)pl.n_instance_values * 32, hipMemcpyHostToDevice, cs));
+        H2V_HIP_CHECK(hipMemcpyAsync(b->tail, rand_tail, 32 * n_tail, hipMemcpyHostToDevice, cs));
         // VK-wide bases sit behind the batch's own points so that one MSM covers both
-        H2V_HIP_CHECK(hipMemcpyAsync(b->pts + n * (size_t)pl.n_points, pd->shared_bases, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, s));
-        H2V_HIP_CHECK(hipMemcpyAsync(b->phi + n * (size_t)pl.n_points, pd->shared_phi, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, s));
+        H2V_HIP_CHECK(hipMemcpyAsync(b->pts + n * (size_t)pl.n_points, pd->shared_bases, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, cs));
+        H2V_HIP_CHECK(hipMemcpyAsync(b->phi + n * (size_t)pl.n_points, pd->shared_phi, sizeof(G1A) * pl.n_shared, hipMemcpyDeviceToDevice, cs));
+        return 0;
+    };
+    if (!overlap) {
+        if ((rc = copy_proofs(s, 0, n)) || (rc = copy_rest(s))) return rc;
+        H2V_HIP_CHECK(hipStreamSynchronize(s));  // the host buffers are the caller's again
+        return 0;
     }
-    H2V_HIP_CHECK(hipStreamSynchronize(s));  // the host buffers are the caller's again
+    // Chunked: [chunk 0] [instances, draws, VK-wide bases] [chunk 1] ... on the copy stream, an event behind each; the batch's stream
+    // decompresses chunk c as soon as it has arrived — while chunk c + 1 (or the instances) is still on the link.  Chunk boundaries
+    // are multiples of 16 proofs (the decompression kernel stores whole 128-byte lines of 72-byte points).
+    if (!b->copy) {
+        H2V_HIP_CHECK(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+        for (int i = 0; i <= H2V_UPLOAD_CHUNKS; ++i) H2V_HIP_CHECK(hipEventCreateWithFlags(&b->ev_chunk[i], hipEventDisableTiming));
+    }
+    H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));                 // what the batch's stream still holds (an earlier launch reading these buffers) comes first
+    H2V_HIP_CHECK(hipStreamWaitEvent(b->copy, b->ev_fork0, 0));
+    StageArgs g{(uint32_t)n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};
+    if ((rc = decompress_begin_enqueue(s, g))) return rc;
+    const size_t chunks = std::max<size_t>(1, std::min<size_t>(H2V_UPLOAD_CHUNKS, n * pl.proof_len / (1u << 20)));   // at least ~1 MB per chunk
+    const size_t per = ((n + chunks - 1) / chunks + 15) / 16 * 16;
+    size_t c = 0;
+    for (size_t p0 = 0; p0 < n; p0 += per, ++c) {
+        const size_t p1 = std::min(n, p0 + per);
+        if ((rc = copy_proofs(b->copy, p0, p1))) return rc;
+        H2V_HIP_CHECK(hipEventRecord(b->ev_chunk[c], b->copy));
+        H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_chunk[c], 0));
+        if ((rc = decompress_range_enqueue(s, g, (uint32_t)p0, (uint32_t)p1))) return rc;
+        if (c == 0) {   // the small inputs travel behind the first chunk, under its decompression
+            if ((rc = copy_rest(b->copy))) return rc;
+            H2V_HIP_CHECK(hipEventRecord(b->ev_chunk[H2V_UPLOAD_CHUNKS], b->copy));
+        }
+    }
+    H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_chunk[H2V_UPLOAD_CHUNKS], 0));
+    if ((rc = decompress_finish_enqueue(s, g))) return rc;
+    b->decompressed = true;
+    H2V_HIP_CHECK(hipStreamSynchronize(b->copy));   // the host buffers are the caller's again (the kernels go on)
     return 0;
 }
 
@@ -143,8 +183,10 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     mark();
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this launch (uploads) is visible to the auxiliary stream
     StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};
-    // stage 1: point decompression + canonicity checks; stage 2: absorbed stream, Blake2b challenges, batch multipliers
-    if ((rc = decompress_stage_enqueue(s, g))) return rc;
+    // stage 1: point decompression + canonicity checks (already on the stream, behind its chunked upload, after h2v_batch_upload_launch);
+    // stage 2: absorbed stream, Blake2b challenges, batch multipliers
+    if (!b->decompressed && (rc = decompress_stage_enqueue(s, g))) return rc;
+    b->decompressed = false;   // (a later h2v_batch_launch on the same upload runs the stage again: every launch does all of its work)
     mark();
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
     // the batch multipliers depend only on the uploaded draws: they run on the auxiliary stream beside decompression and transcript
@@ -451,6 +493,8 @@ void h2v_batch_destroy(h2v_batch* b) {
     b->ws.release();
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     if (b->aux) { hipStreamSynchronize(b->aux); hipStreamDestroy(b->aux); }
+    if (b->copy) { hipStreamSynchronize(b->copy); hipStreamDestroy(b->copy); }
+    for (int i = 0; i <= H2V_UPLOAD_CHUNKS; ++i) if (b->ev_chunk[i]) hipEventDestroy(b->ev_chunk[i]);
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
     if (b->ev_join) hipEventDestroy(b->ev_join);
     if (b->ev_fork0) hipEventDestroy(b->ev_fork0);
@@ -464,6 +508,12 @@ int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t 
     return upload_impl(b, n, proofs_flat, proof_len, instances_flat, n_instance_columns, col_lens, rand32_tail, n_tail);
 }
 int h2v_batch_launch(h2v_batch* b, int with_pairing) { return launch_impl(b, with_pairing); }
+int h2v_batch_upload_launch(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len, const uint8_t* instances_flat, size_t n_instance_columns,
+                            const size_t* col_lens, const uint8_t* rand32_tail, size_t n_tail, int with_pairing) {
+    int rc = upload_impl(b, n, proofs_flat, proof_len, instances_flat, n_instance_columns, col_lens, rand32_tail, n_tail, true);
+    if (rc) return rc;
+    return launch_impl(b, with_pairing);
+}
 int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]) {
     if (b && b->groups > 1) { set_last_error("h2v_batch_finish: the batch is grouped, use h2v_batch_finish_groups"); return H2V_ERR_BAD_ARGUMENT; }
     return finish_impl(b, per_proof_status, batch_ok, out_left_xy, out_right_xy);

@@ -590,6 +590,27 @@ int decompress_stage_enqueue(hipStream_t s, const StageArgs& g) {
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
+int decompress_begin_enqueue(hipStream_t s, const StageArgs& g) {
+    if (g.n) H2V_HIP_CHECK(hipMemsetAsync(g.status, 0, sizeof(int) * g.n, s));
+    return 0;
+}
+int decompress_range_enqueue(hipStream_t s, const StageArgs& g, uint32_t p0, uint32_t p1) {
+    if (p1 <= p0) return 0;
+    const Plan& pl = *g.plan;
+    const uint32_t m = p1 - p0, tp = m * pl.n_points;
+    if (!tp) return 0;
+    hipLaunchKernelGGL(k_decompress, dim3((tp + 63) / 64), dim3(64), 0, s, g.proofs + (size_t)p0 * pl.proof_len, pl.proof_len, g.pd->point_offsets, pl.n_points, pl.n_main_points, m,
+                       g.pts + (size_t)p0 * pl.n_points, g.phi + (size_t)p0 * pl.n_points, g.ycanon + (size_t)p0 * pl.n_points * 32, g.status + p0);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int decompress_finish_enqueue(hipStream_t s, const StageArgs& g) {
+    const Plan& pl = *g.plan;
+    const uint32_t ts = g.n * (pl.n_scalars + pl.n_instance_values);
+    if (ts) hipLaunchKernelGGL(k_check_scalars, dim3((ts + 255) / 256), dim3(256), 0, s, g.proofs, pl.proof_len, g.pd->scalar_offsets, pl.n_scalars, g.inst, pl.n_instance_values, g.n, g.status);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int transcript_stage_enqueue(hipStream_t s, const StageArgs& g) {
     const uint32_t n = g.n;
     if (!n) return 0;

@@ -170,6 +170,19 @@ class ShardedBatch:
         self.gathered = gathered      # kept alive until finish()
         self.batch.fold_check_enqueue(gathered.data_ptr(), n_records)
 
+    def upload_launch(self, proofs_flat: bytes, proof_len: int, instances_flat: bytes, col_lens, rand_tail: bytes):
+        """upload() + launch() with the host -> device copy of the shard hidden behind its point decompression
+        (h2v_batch_upload_launch): for shards that arrive from the host for every batch."""
+        if self.world == 1 and not self.always_exchange:
+            self.batch.upload_launch(proofs_flat, proof_len, instances_flat, col_lens, rand_tail, with_pairing=True)
+            return
+        import torch
+        ctxm = torch.cuda.stream(self._external_stream()) if (self.device.type == "cuda" and self._stream_handle is not None) else _NullCtx()
+        with ctxm:
+            self.batch.upload_launch(proofs_flat, proof_len, instances_flat, col_lens, rand_tail, with_pairing=False)
+            self.batch.export_accumulators(self.records.data_ptr())
+            self.fold(gather_accumulators(self.records, self.world, self.group), self.world)
+
     def launch(self):
         if self.world == 1 and not self.always_exchange:
             self.batch.launch(with_pairing=True)

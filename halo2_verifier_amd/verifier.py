@@ -494,6 +494,20 @@ class Batch:
     def launch(self, with_pairing=True):
         check(self._lib.h2v_batch_launch(self._h, 1 if with_pairing else 0))
 
+    def upload_launch(self, proofs_flat: bytes, proof_len: int, instances_flat: bytes, col_lens, rand_tail=None, with_pairing=True):
+        """upload() + launch() with the host -> device copy hidden behind the point decompression (h2v_batch_upload_launch)."""
+        n = len(proofs_flat) // proof_len if proof_len else 0
+        if proof_len and len(proofs_flat) != n * proof_len:
+            raise ValueError("proofs_flat is not a whole number of proofs")
+        if len(instances_flat) != n * sum(col_lens) * 32:
+            raise ValueError(f"instances_flat must be n * sum(col_lens) * 32 = {n * sum(col_lens) * 32} bytes, got {len(instances_flat)}")
+        if rand_tail is not None and len(rand_tail) % 32:
+            raise ValueError("rand_tail is not a whole number of 32-byte scalars")
+        cl = (ctypes.c_size_t * max(len(col_lens), 1))(*col_lens)
+        nt = len(rand_tail) // 32 if rand_tail is not None else 0
+        check(self._lib.h2v_batch_upload_launch(self._h, n, proofs_flat, proof_len, instances_flat, len(col_lens), cl, rand_tail, nt, 1 if with_pairing else 0))
+        self.n = n
+
     def export_accumulators(self, device_dst: int):
         check(self._lib.h2v_batch_export_accumulators(self._h, ctypes.c_void_p(device_dst)))
 

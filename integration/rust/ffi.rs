@@ -85,6 +85,8 @@ extern "C" {
     pub fn h2v_batch_upload(b: *mut h2v_batch, n: usize, proofs_flat: *const u8, proof_len: usize, instances_flat: *const u8,
                             n_instance_columns: usize, col_lens: *const usize, rand32_tail: *const u8, n_tail: usize) -> c_int;
     pub fn h2v_batch_launch(b: *mut h2v_batch, with_pairing: c_int) -> c_int;
+    pub fn h2v_batch_upload_launch(b: *mut h2v_batch, n: usize, proofs_flat: *const u8, proof_len: usize, instances_flat: *const u8,
+                                   n_instance_columns: usize, col_lens: *const usize, rand32_tail: *const u8, n_tail: usize, with_pairing: c_int) -> c_int;
     pub fn h2v_batch_finish(b: *mut h2v_batch, per_proof_status: *mut c_int, batch_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8) -> c_int;
     pub fn h2v_batch_set_groups(b: *mut h2v_batch, groups: usize) -> c_int;
     pub fn h2v_batch_finish_groups(b: *mut h2v_batch, per_proof_status: *mut c_int, group_ok: *mut c_int, out_left_xy: *mut u8, out_right_xy: *mut u8,

@@ -144,3 +144,40 @@ def test_verify_each_beyond_one_launch(pool):
     for i in (0, 5, 512, 513, 600, 1023, 1024, 1099, 2, 700):
         assert circuits.oracle_verify_single(s, Pn[i], In[i]) == expect[i], i
     ctx.close()
+
+
+@pytest.mark.parametrize("G,gs,proof_len", [(1, 37, 1024), (4, 1024, 1024), (20, 1024, 1024), (3, 500, 1056)])
+def test_upload_launch_equals_upload_then_launch(pool, G, gs, proof_len):
+    """h2v_batch_upload_launch (the host -> device copy chunked under the point decompression) gives what upload + launch give:
+    one chunk (small batches), several chunks, the driver's 20 x 1024 shape, proofs with trailing bytes (strided copy); a spoiled
+    proof in the last chunk keeps its status; and a plain re-launch afterwards runs every stage again."""
+    import halo2_verifier_amd as h2v
+    s, P, I = pool
+    ctx = _ctx(s)
+    rnd = random.Random(G * 7 + gs)
+    n = G * gs
+    idx = [(13 * i) % len(P) for i in range(n)]
+    Pn = [P[i] + bytes(proof_len - 1024) for i in idx]
+    In = [I[i] for i in idx]
+    bad = bytearray(Pn[n - 2]); bad[32:64] = b"\xff" * 32; Pn[n - 2] = bytes(bad)
+    rand = b"".join(rnd.randrange(1, R_MOD).to_bytes(32, "little") for _ in range(n))
+    flat, inst = _flat(Pn, In)
+    a = h2v.Batch(ctx, n, 8, groups=G)
+    a.upload(flat, proof_len, inst, [8], rand)
+    a.launch(with_pairing=True)
+    ref = a.finish_groups()
+    a.close()
+    b = h2v.Batch(ctx, n, 8, groups=G)
+    b.upload_launch(flat, proof_len, inst, [8], rand, with_pairing=True)
+    got = b.finish_groups()
+    assert got == ref and got[1][n - 2] == -5 and got[0][:-1] == [True] * (G - 1) and got[0][-1] is False
+    b.launch(with_pairing=True)                 # the same upload launched again: decompression included
+    assert b.finish_groups() == ref
+    # a second upload_launch into the same object with other inputs (buffers reused, events reused)
+    good = bytes(Pn[n - 2][:32]) + P[idx[n - 2]][32:] + bytes(proof_len - 1024)
+    flat2 = flat[: (n - 2) * proof_len] + P[idx[n - 2]] + bytes(proof_len - 1024) + flat[(n - 1) * proof_len:]
+    b.upload_launch(flat2, proof_len, inst, [8], rand, with_pairing=True)
+    ok2, st2, _, _ = b.finish_groups()
+    assert ok2 == [True] * G and st2 == [0] * n
+    b.close()
+    ctx.close()
