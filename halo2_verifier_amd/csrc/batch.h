@@ -75,7 +75,8 @@ int decompress_stage_enqueue(hipStream_t s, const StageArgs& g);
 // the same stage in pieces (h2v_batch_upload_launch): reset the status words; decompress the points of proofs [p0, p1); check the
 // scalars of all proofs
 int decompress_begin_enqueue(hipStream_t s, const StageArgs& g);
-int decompress_range_enqueue(hipStream_t s, const StageArgs& g, uint32_t p0, uint32_t p1);
+// (src / src_stride: read the proof bytes from there instead of g.proofs — the caller's host buffer, h2v_batch_upload_launch)
+int decompress_range_enqueue(hipStream_t s, const StageArgs& g, uint32_t p0, uint32_t p1, const uint8_t* src = nullptr, uint32_t src_stride = 0);
 int decompress_finish_enqueue(hipStream_t s, const StageArgs& g);
 int transcript_stage_enqueue(hipStream_t s, const StageArgs& g);
 // groups > 1: group g owns proofs [g*n/groups, ..) and the draws tail[g*n_tail/groups, ..)
@@ -93,10 +94,9 @@ struct h2v_batch {
     bool owns_stream = true;
     hipStream_t aux = nullptr;        // the accumulators' affine conversion runs here, beside the pairing (both only read them)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
-    // h2v_batch_upload_launch: the host -> device copies run on `copy`, chunk by chunk, an event behind each; the decompression of a
-    // chunk waits for its event only, so it overlaps the copy of the next chunk
+    // h2v_batch_upload_launch: the host -> device copies run on `copy`, chunk by chunk, each followed (after the blocking copy has
+    // returned) by the decompression of that chunk on `stream`
     hipStream_t copy = nullptr;
-    hipEvent_t ev_chunk[H2V_UPLOAD_CHUNKS + 1] = {nullptr};
     bool decompressed = false;        // the next launch finds its points already decompressed (set by h2v_batch_upload_launch)
     size_t max_proofs = 0, max_inst = 0;
     h2v::PlanDevice* plan = nullptr;  // set at upload (depends on the instance shape)

@@ -3,6 +3,7 @@
 #include "../../include/h2v.h"
 #include "batch.h"
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <stdio.h>
 
@@ -129,35 +130,45 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
         H2V_HIP_CHECK(hipStreamSynchronize(s));  // the host buffers are the caller's again
         return 0;
     }
-    // Chunked: [chunk 0] [instances, draws, VK-wide bases] [chunk 1] ... on the copy stream, an event behind each; the batch's stream
-    // decompresses chunk c as soon as it has arrived — while chunk c + 1 (or the instances) is still on the link.  Chunk boundaries
-    // are multiples of 16 proofs (the decompression kernel stores whole 128-byte lines of 72-byte points).
-    if (!b->copy) {
-        H2V_HIP_CHECK(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
-        for (int i = 0; i <= H2V_UPLOAD_CHUNKS; ++i) H2V_HIP_CHECK(hipEventCreateWithFlags(&b->ev_chunk[i], hipEventDisableTiming));
+    // Overlapped form (h2v_batch_upload_launch).  What was measured on the way (profiles/r03_h2d_microbench.txt, r03_upload_timeline.txt):
+    //  * a 26 MB copy takes 0.47 ms from pageable and from pinned memory alike, and an "asynchronous" copy out of pageable memory
+    //    returns only when the data is on the device — the calling thread is the one thing it blocks;
+    //  * chunks on a second stream with an event per chunk for the kernels to wait on: erratic (0.64 ms best, 1.8 ms mean for eight
+    //    chunks) — cross-stream event waits set the pace, slower than one blocking copy;
+    //  * decompression in chunks, each enqueued when its chunk has arrived: point decompression is ONE round of ~0.5 ms of dependent
+    //    work per lane whatever the launch size, so eight chunk launches are eight rounds (4.2 ms per launch instead of 3.6);
+    //  * a decompression kernel reading the caller's registered buffer over the link: 0.82 ms instead of 0.60; a gather kernel for
+    //    the point bytes alone: 0.23 ms — and hipHostUnregister waits for EVERY kernel in flight on the device (3.0 ms behind a 3 ms
+    //    kernel, tools/unregister_probe.hip), so a registration cannot be dropped before the launch it helped has finished.
+    // What is left: the decompression needs only the POINT bytes of a proof (12 x 32 of 1024 bytes for the headline VK), and those lie in
+    // a few runs at fixed offsets.  The thread copies the point runs first (strided copies, a third of the bytes), enqueues the ONE
+    // decompression launch — when the blocking copy has returned the bytes are in device memory, so no event is needed — and copies
+    // everything (whole proofs, instances, draws) while the GPU decompresses; the later stages are enqueued after that copy returned.
+    std::vector<std::pair<uint32_t, uint32_t>> runs;   // (offset, length) of the maximal runs of point bytes inside a proof
+    {
+        std::vector<uint32_t> offs(pl.point_offsets);
+        std::sort(offs.begin(), offs.end());
+        for (uint32_t o : offs) { if (!runs.empty() && runs.back().first + runs.back().second == o) runs.back().second += 32; else runs.push_back({o, 32u}); }
     }
-    H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));                 // what the batch's stream still holds (an earlier launch reading these buffers) comes first
-    H2V_HIP_CHECK(hipStreamWaitEvent(b->copy, b->ev_fork0, 0));
+    size_t point_bytes = 0;
+    for (auto& r : runs) point_bytes += r.second;
+    if (runs.size() > 4 || 2 * point_bytes > pl.proof_len) {   // points all over the proof, or most of it: nothing to gain
+        if ((rc = copy_proofs(s, 0, n)) || (rc = copy_rest(s))) return rc;
+        H2V_HIP_CHECK(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (!b->copy) H2V_HIP_CHECK(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+    H2V_HIP_CHECK(hipStreamSynchronize(s));   // an earlier launch of this batch may still read the buffers (normally long finished: h2v_batch_finish)
+    for (auto& r : runs) H2V_HIP_CHECK(hipMemcpy2DAsync(b->proofs + r.first, pl.proof_len, proofs_flat + r.first, proof_len, r.second, n, hipMemcpyHostToDevice, b->copy));
+    H2V_HIP_CHECK(hipStreamSynchronize(b->copy));
     StageArgs g{(uint32_t)n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};
     if ((rc = decompress_begin_enqueue(s, g))) return rc;
-    const size_t chunks = std::max<size_t>(1, std::min<size_t>(H2V_UPLOAD_CHUNKS, n * pl.proof_len / (1u << 20)));   // at least ~1 MB per chunk
-    const size_t per = ((n + chunks - 1) / chunks + 15) / 16 * 16;
-    size_t c = 0;
-    for (size_t p0 = 0; p0 < n; p0 += per, ++c) {
-        const size_t p1 = std::min(n, p0 + per);
-        if ((rc = copy_proofs(b->copy, p0, p1))) return rc;
-        H2V_HIP_CHECK(hipEventRecord(b->ev_chunk[c], b->copy));
-        H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_chunk[c], 0));
-        if ((rc = decompress_range_enqueue(s, g, (uint32_t)p0, (uint32_t)p1))) return rc;
-        if (c == 0) {   // the small inputs travel behind the first chunk, under its decompression
-            if ((rc = copy_rest(b->copy))) return rc;
-            H2V_HIP_CHECK(hipEventRecord(b->ev_chunk[H2V_UPLOAD_CHUNKS], b->copy));
-        }
-    }
-    H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_chunk[H2V_UPLOAD_CHUNKS], 0));
+    if ((rc = decompress_range_enqueue(s, g, 0, (uint32_t)n))) return rc;
+    // (the whole proofs again, point bytes included: identical bytes over the ones the kernel is reading)
+    if ((rc = copy_proofs(b->copy, 0, n)) || (rc = copy_rest(b->copy))) return rc;
+    H2V_HIP_CHECK(hipStreamSynchronize(b->copy));   // everything is on the device; the host buffers are the caller's again
     if ((rc = decompress_finish_enqueue(s, g))) return rc;
     b->decompressed = true;
-    H2V_HIP_CHECK(hipStreamSynchronize(b->copy));   // the host buffers are the caller's again (the kernels go on)
     return 0;
 }
 
@@ -494,7 +505,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     for (int i = 0; i < 8; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     if (b->aux) { hipStreamSynchronize(b->aux); hipStreamDestroy(b->aux); }
     if (b->copy) { hipStreamSynchronize(b->copy); hipStreamDestroy(b->copy); }
-    for (int i = 0; i <= H2V_UPLOAD_CHUNKS; ++i) if (b->ev_chunk[i]) hipEventDestroy(b->ev_chunk[i]);
+
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
     if (b->ev_join) hipEventDestroy(b->ev_join);
     if (b->ev_fork0) hipEventDestroy(b->ev_fork0);

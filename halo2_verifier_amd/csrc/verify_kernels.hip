@@ -594,12 +594,13 @@ int decompress_begin_enqueue(hipStream_t s, const StageArgs& g) {
     if (g.n) H2V_HIP_CHECK(hipMemsetAsync(g.status, 0, sizeof(int) * g.n, s));
     return 0;
 }
-int decompress_range_enqueue(hipStream_t s, const StageArgs& g, uint32_t p0, uint32_t p1) {
+int decompress_range_enqueue(hipStream_t s, const StageArgs& g, uint32_t p0, uint32_t p1, const uint8_t* src, uint32_t src_stride) {
     if (p1 <= p0) return 0;
     const Plan& pl = *g.plan;
     const uint32_t m = p1 - p0, tp = m * pl.n_points;
     if (!tp) return 0;
-    hipLaunchKernelGGL(k_decompress, dim3((tp + 63) / 64), dim3(64), 0, s, g.proofs + (size_t)p0 * pl.proof_len, pl.proof_len, g.pd->point_offsets, pl.n_points, pl.n_main_points, m,
+    if (!src) { src = g.proofs; src_stride = pl.proof_len; }
+    hipLaunchKernelGGL(k_decompress, dim3((tp + 63) / 64), dim3(64), 0, s, src + (size_t)p0 * src_stride, src_stride, g.pd->point_offsets, pl.n_points, pl.n_main_points, m,
                        g.pts + (size_t)p0 * pl.n_points, g.phi + (size_t)p0 * pl.n_points, g.ycanon + (size_t)p0 * pl.n_points * 32, g.status + p0);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;

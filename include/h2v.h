@@ -243,12 +243,12 @@ int h2v_batch_upload(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t 
                      const uint8_t* rand32_tail, size_t n_tail);
 /* Enqueue decompress -> transcript -> Fr program -> fold -> MSM (-> pairing if with_pairing). */
 int h2v_batch_launch(h2v_batch* b, int with_pairing);
-/* h2v_batch_upload followed by h2v_batch_launch, with the host -> device copy HIDDEN behind the first stage: the proofs travel in up
- * to 8 chunks on a copy stream of the batch, and the point decompression of a chunk is enqueued behind that chunk's arrival — it runs
- * while the next chunk (and the instances and draws, which follow the first chunk) is still on the link.  Same results as the two
- * calls; returns when the host buffers are the caller's again, with the launch still running (h2v_batch_finish waits for it).
- * For callers whose proofs arrive from the host for every batch (the C ABI hands over host memory): a single launch has nothing
- * else to hide the PCIe copy behind. */
+/* h2v_batch_upload followed by h2v_batch_launch, with most of the host -> device copy HIDDEN behind the first stage: only the point
+ * bytes of the proofs (a few runs at fixed offsets: 12 x 32 of 1024 bytes for the headline VK) are copied first, the point
+ * decompression is enqueued, and the calling thread copies everything — whole proofs, instances, draws — while the GPU decompresses.
+ * Same results as the two calls; returns when the host buffers are the caller's again, with the launch still running
+ * (h2v_batch_finish waits for it).  For callers whose proofs arrive from the host for every batch (the C ABI hands over host
+ * memory): a single launch has nothing else to hide the PCIe copy behind. */
 int h2v_batch_upload_launch(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len,
                             const uint8_t* instances_flat, size_t n_instance_columns, const size_t* col_lens,
                             const uint8_t* rand32_tail, size_t n_tail, int with_pairing);
