@@ -208,8 +208,8 @@ def traffic_record(terms_per_launch):
     _, path, t, b, tj = best
     rel = os.path.relpath(path, ROOT)
     if t == terms_per_launch:
-        return b, f"{rel} (same launch shape: {t} terms per launch; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes)", tj
-    return b * terms_per_launch / t, f"{rel} scaled per term ({t} -> {terms_per_launch} terms per launch; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes)", tj
+        return b, f"{rel} (same launch shape: {t} terms per launch; fetch_factor x FETCH_SIZE + WRITE_SIZE with the per-kernel factor of profiles/r03_fetch_calibration.txt: 1 for msm_accumulate's gathers, 2 for streams and whole-line reads)", tj
+    return b * terms_per_launch / t, f"{rel} scaled per term ({t} -> {terms_per_launch} terms per launch; per-kernel fetch factors of profiles/r03_fetch_calibration.txt)", tj
 
 
 def _median(v):
@@ -518,7 +518,9 @@ def rank_main(args):
             pass
         kernels = {"msm_accumulate": {"ms": acc_ms, "ms_timed_region": stages.get("msm_accumulate", 0.0),
                                       "timing": "the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL events), every launch of the timed region", "alg_GBps": (96.0 * terms_total) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None,
-                                      "valu_active": valu, "valu_active_source": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the committed --pmc pass named in traffic_source"}}
+                                      "valu_active": valu, "valu_active_source": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the committed --pmc pass named in traffic_source",
+                                      "alu_frac": (2 * 12 * 11 * terms_total) / (acc_ms * 1e-3) / 168e9 if acc_ms > 0 else None,
+                                      "alu_frac_note": "Fq products/s of the kernel (11 per mixed addition, 2 x 12 additions per term) over the measured chip-wide peak of the Montgomery product, 168 G/s (tools/limb29_microbench.hip)"}}
         workload = (f"batch {B} proofs/GPU/step, k={K_CIRCUIT}, vector_mul VK (3 advice, 1 fixed, 1 instance col with {N_PUBLIC} public inputs, 4 permutation cols), "
                     f"SHPLONK/Blake2b, AccumulatorStrategy (one pairing per step" + (f" for all {world} x {B} proofs" if world > 1 else "") + f"), {args.distinct} distinct proofs; "
                     f"{G} steps per launch (grouped batch), {depth} launches in flight" + (f", + one launch of {m['rem']} steps" if m["rem"] else ""))

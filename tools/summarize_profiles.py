@@ -15,6 +15,19 @@ import sys
 from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
+
+# FETCH_SIZE -> bytes, per kernel, from the calibration of the access patterns (profiles/r03_fetch_calibration.txt): wide (whole-line)
+# reads are counted at half their size on gfx950, sub-line gathers in full.  WRITE_SIZE is exact for every pattern measured.
+FETCH_FACTOR_DEFAULT = 2.0
+FETCH_FACTOR = {"h2v::msm_accumulate": (1.0, "72-B base gathers: rows k_gather72 / k_gather72_big count the straddled sectors in full; its streamed list reads (4 B per entry) are < 4 % of its fetches")}
+FETCH_REASON_DEFAULT = "coalesced streams / whole 128-byte slots: rows k_stream_read, k_stream4, k_gather128 count half"
+
+
+def fetch_factor(kernel):
+    for k, (f, why) in FETCH_FACTOR.items():
+        if kernel.startswith(k):
+            return f, why
+    return FETCH_FACTOR_DEFAULT, FETCH_REASON_DEFAULT
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -105,11 +118,15 @@ for shape, pre, cmd in (("steps20", "drv", "python3 bench.py --gpus 1 --steps 20
     per_all = {k: {"FETCH_SIZE": fetch.get((k, "FETCH_SIZE"), (0, 0))[0], "WRITE_SIZE": write.get((k, "WRITE_SIZE"), (0, 0))[0]} for k in allk}
     fk, wk = sum(v["FETCH_SIZE"] for v in per.values()), sum(v["WRITE_SIZE"] for v in per.values())
     terms = b1.get("roofline", {}).get("terms_per_launch")
+    per_bytes = {k: (fetch_factor(k)[0] * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 for k, v in per.items()}
     json.dump({
         "source": f"profiles/{tag}_pmc_fetch_write_{shape}.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; {cmd}; %s steps per launch)" % b1.get("config", {}).get("steps_per_launch"),
-        "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE reads half of wide coalesced fetches on gfx950 (MI355X_MICROARCH.md, HBM)",
+        "correction": {"rule": "bytes = (fetch_factor * FETCH_SIZE + WRITE_SIZE) * 1024, fetch_factor per kernel from the calibrated access patterns (profiles/r03_fetch_calibration.txt)",
+                       "per_kernel": {k: {"fetch_factor": fetch_factor(k)[0], "calibration": fetch_factor(k)[1]} for k in msm},
+                       "round2": "round 2 doubled FETCH_SIZE for every kernel: %.0f bytes for this launch" % ((2 * fk + wk) * 1024)},
         "fetch_kb": fk, "write_kb": wk,
-        "msm_stage_traffic_bytes_per_launch": (2 * fk + wk) * 1024,
+        "msm_stage_traffic_bytes_per_launch": sum(per_bytes.values()),
+        "per_kernel_bytes": per_bytes,
         "terms_per_launch": terms,
         "algorithmic_bytes_per_launch": 96 * terms if terms else None,
         "msm_kernel_avg_ns": {k: avg_drv.get(k) for k in msm} if shape == "steps20" else None,
