@@ -351,11 +351,17 @@ def _lagrange_at(points, evals, u):
     return total
 
 
-def guard(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
+def guard(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B, circuit_instances=1):
     """Returns dict(challenges, right=[(scalar, point)], left=[(scalar, point)]) or raises (ValueError: transcript
-    error with .args[1] in {"transcript", "opening"}; ZeroDivisionError: the reference would panic)."""
+    error with .args[1] in {"transcript", "opening"}; ZeroDivisionError: the reference would panic).
+    circuit_instances = M = `instances.len()` of verify_proof (lib.rs:43): `instances` then holds the M x columns of the M circuit
+    instances that share the transcript, instance by instance; every per-instance read / expression / query below is repeated
+    in the reference's order (lib.rs:76-161 reads, :220-253 evaluations, :273-346 expressions, :349-391 queries)."""
     n, k = 1 << vk["k"], vk["k"]
-    if len(instances) != vk["num_instance"]: raise ValueError("InvalidInstances", "invalid_instances")
+    M = circuit_instances
+    if len(instances) != M * vk["num_instance"]: raise ValueError("InvalidInstances", "invalid_instances")
+    NI = vk["num_instance"]
+    inst_of = [instances[q * NI:(q + 1) * NI] for q in range(M)]
     omega = ROOT_OF_UNITY
     for _ in range(S - k): omega = omega * omega % R
     omega_inv = pow(omega, -1, R)
@@ -366,22 +372,24 @@ def guard(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
         for col in instances:
             for v in col: tr.common_scalar(v)
         A, Ch = vk["num_advice"], vk["num_challenges"]
-        advice_c, challenges = [None] * A, [0] * Ch
+        advice_c, challenges = [[None] * A for _ in range(M)], [0] * Ch
         for phase in range(max(vk["advice_phase"], default=0) + 1):
-            for i in range(A):
-                if vk["advice_phase"][i] == phase: advice_c[i] = tr.read_point()
+            for q in range(M):
+                for i in range(A):
+                    if vk["advice_phase"][i] == phase: advice_c[q][i] = tr.read_point()
             for i in range(Ch):
                 if vk["challenge_phase"][i] == phase: challenges[i] = tr.squeeze()
         theta = tr.squeeze()
         L, Sh, Pn = len(vk["lookups"]), len(vk["shuffles"]), len(vk["perm_columns"])
-        lk_in, lk_tab = [None] * L, [None] * L
-        for i in range(L): lk_in[i] = tr.read_point(); lk_tab[i] = tr.read_point()
+        lk_in, lk_tab = [[None] * L for _ in range(M)], [[None] * L for _ in range(M)]
+        for q in range(M):
+            for i in range(L): lk_in[q][i] = tr.read_point(); lk_tab[q][i] = tr.read_point()
         beta, gamma = tr.squeeze(), tr.squeeze()
         chunk = vk["cs_degree"] - 2
         nsets = (Pn + chunk - 1) // chunk if Pn else 0
-        perm_z = [tr.read_point() for _ in range(nsets)]
-        lk_z = [tr.read_point() for _ in range(L)]
-        sh_z = [tr.read_point() for _ in range(Sh)]
+        perm_z = [[tr.read_point() for _ in range(nsets)] for _ in range(M)]
+        lk_z = [[tr.read_point() for _ in range(L)] for _ in range(M)]
+        sh_z = [[tr.read_point() for _ in range(Sh)] for _ in range(M)]
         random_c = tr.read_point()
         y = tr.squeeze()
         H = vk["cs_degree"] - 1
@@ -389,20 +397,26 @@ def guard(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
         x = tr.squeeze()
         xn = pow(x, n, R)
         n_inv = pow(n, -1, R)
-        def l_i(i): return rot(pow((x - rot(1, i)) % R, -1, R) * ((xn - 1) * n_inv % R) % R, i)
+        l_cache = {}
+        def l_i(i):
+            if i not in l_cache: l_cache[i] = rot(pow((x - rot(1, i)) % R, -1, R) * ((xn - 1) * n_inv % R) % R, i)
+            return l_cache[i]
         inst_evals = []
-        for col, r_ in vk["instance_queries"]:
-            inst_evals.append(sum(v * l_i(j - r_) for j, v in enumerate(instances[col])) % R)
-        adv_e = [tr.read_scalar() for _ in vk["advice_queries"]]
+        for q in range(M):
+            inst_evals.append([sum(v * l_i(j - r_) for j, v in enumerate(inst_of[q][col])) % R for col, r_ in vk["instance_queries"]])
+        adv_e = [[tr.read_scalar() for _ in vk["advice_queries"]] for _ in range(M)]
         fix_e = [tr.read_scalar() for _ in vk["fixed_queries"]]
         random_e = tr.read_scalar()
         sig_e = [tr.read_scalar() for _ in range(Pn)]
         pz = []
-        for i in range(nsets):
-            e, nx = tr.read_scalar(), tr.read_scalar()
-            pz.append((e, nx, tr.read_scalar() if i + 1 < nsets else None))
-        lk_e = [[tr.read_scalar() for _ in range(5)] for _ in range(L)]   # product, product_next, input, input_inv, table
-        sh_e = [[tr.read_scalar() for _ in range(2)] for _ in range(Sh)]
+        for q in range(M):
+            pzq = []
+            for i in range(nsets):
+                e, nx = tr.read_scalar(), tr.read_scalar()
+                pzq.append((e, nx, tr.read_scalar() if i + 1 < nsets else None))
+            pz.append(pzq)
+        lk_e = [[[tr.read_scalar() for _ in range(5)] for _ in range(L)] for _ in range(M)]   # product, product_next, input, input_inv, table
+        sh_e = [[[tr.read_scalar() for _ in range(2)] for _ in range(Sh)] for _ in range(M)]
     except ValueError as e:
         raise ValueError(e.args[0], "transcript")
 
@@ -410,72 +424,76 @@ def guard(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
     l_last, l_0 = l_i(-(bf + 1)), l_i(0)
     l_blind = sum(l_i(r_) for r_ in range(-bf, 0)) % R
     cv = vk["coeff_vals"]
-    ev = lambda t: _eval_expr(t, cv, adv_e, fix_e, inst_evals, challenges)
-    exprs = [ev(g) for g in vk["gates"]]
-    def col_eval(col):
-        idx, typ = col
-        if typ <= 2: return adv_e[[i for i, q in enumerate(vk["advice_queries"]) if q[0] == idx and q[2] == 0][0]]
-        if typ == 255: return fix_e[[i for i, q in enumerate(vk["fixed_queries"]) if q[0] == idx and q[1] == 0][0]]
-        return inst_evals[[i for i, q in enumerate(vk["instance_queries"]) if q[0] == idx and q[1] == 0][0]]
     active = (1 - (l_last + l_blind)) % R
-    if nsets:
-        exprs.append(l_0 * (1 - pz[0][0]) % R)
-        exprs.append((pz[-1][0] * pz[-1][0] - pz[-1][0]) * l_last % R)
-        for i in range(1, nsets): exprs.append((pz[i][0] - pz[i - 1][2]) * l_0 % R)
-        for ci in range(nsets):
-            cols = vk["perm_columns"][ci * chunk:(ci + 1) * chunk]
-            left, right = pz[ci][1], pz[ci][0]
-            cur = beta * x % R * pow(DELTA, ci * chunk, R) % R
-            for j, col in enumerate(cols):
-                v = col_eval(col)
-                left = left * ((v + beta * sig_e[ci * chunk + j] + gamma) % R) % R
-                right = right * ((v + cur + gamma) % R) % R
-                cur = cur * DELTA % R
+    exprs = []
+    for q in range(M):
+        ev = lambda t, q=q: _eval_expr(t, cv, adv_e[q], fix_e, inst_evals[q], challenges)
+        exprs += [ev(g) for g in vk["gates"]]
+        def col_eval(col, q=q):
+            idx, typ = col
+            if typ <= 2: return adv_e[q][[i for i, qq in enumerate(vk["advice_queries"]) if qq[0] == idx and qq[2] == 0][0]]
+            if typ == 255: return fix_e[[i for i, qq in enumerate(vk["fixed_queries"]) if qq[0] == idx and qq[1] == 0][0]]
+            return inst_evals[q][[i for i, qq in enumerate(vk["instance_queries"]) if qq[0] == idx and qq[1] == 0][0]]
+        if nsets:
+            pq = pz[q]
+            exprs.append(l_0 * (1 - pq[0][0]) % R)
+            exprs.append((pq[-1][0] * pq[-1][0] - pq[-1][0]) * l_last % R)
+            for i in range(1, nsets): exprs.append((pq[i][0] - pq[i - 1][2]) * l_0 % R)
+            for ci in range(nsets):
+                cols = vk["perm_columns"][ci * chunk:(ci + 1) * chunk]
+                left, right = pq[ci][1], pq[ci][0]
+                cur = beta * x % R * pow(DELTA, ci * chunk, R) % R
+                for j, col in enumerate(cols):
+                    v = col_eval(col)
+                    left = left * ((v + beta * sig_e[ci * chunk + j] + gamma) % R) % R
+                    right = right * ((v + cur + gamma) % R) % R
+                    cur = cur * DELTA % R
+                exprs.append((left - right) * active % R)
+        def compress(es, ev=ev):
+            acc = 0
+            for e in es: acc = (acc * theta + ev(e)) % R
+            return acc
+        for i in range(L):
+            z, zn, a_, ai, s_ = lk_e[q][i]
+            exprs.append(l_0 * (1 - z) % R)
+            exprs.append(l_last * (z * z - z) % R)
+            left = zn * (a_ + beta) % R * (s_ + gamma) % R
+            right = z * (compress(vk["lookups"][i][0]) + beta) % R * (compress(vk["lookups"][i][1]) + gamma) % R
             exprs.append((left - right) * active % R)
-    def compress(es):
-        acc = 0
-        for e in es: acc = (acc * theta + ev(e)) % R
-        return acc
-    for i in range(L):
-        z, zn, a_, ai, s_ = lk_e[i]
-        exprs.append(l_0 * (1 - z) % R)
-        exprs.append(l_last * (z * z - z) % R)
-        left = zn * (a_ + beta) % R * (s_ + gamma) % R
-        right = z * (compress(vk["lookups"][i][0]) + beta) % R * (compress(vk["lookups"][i][1]) + gamma) % R
-        exprs.append((left - right) * active % R)
-        exprs.append(l_0 * (a_ - s_) % R)
-        exprs.append((a_ - s_) * (a_ - ai) % R * active % R)
-    for i in range(Sh):
-        z, zn = sh_e[i]
-        exprs.append(l_0 * (1 - z) % R)
-        exprs.append(l_last * (z * z - z) % R)
-        left = zn * (compress(vk["shuffles"][i][1]) + gamma) % R
-        right = z * (compress(vk["shuffles"][i][0]) + gamma) % R
-        exprs.append((left - right) * active % R)
+            exprs.append(l_0 * (a_ - s_) % R)
+            exprs.append((a_ - s_) * (a_ - ai) % R * active % R)
+        for i in range(Sh):
+            z, zn = sh_e[q][i]
+            exprs.append(l_0 * (1 - z) % R)
+            exprs.append(l_last * (z * z - z) % R)
+            left = zn * (compress(vk["shuffles"][i][1]) + gamma) % R
+            right = z * (compress(vk["shuffles"][i][0]) + gamma) % R
+            exprs.append((left - right) * active % R)
     h_eval = 0
     for e in exprs: h_eval = (h_eval * y + e) % R
     if (xn - 1) % R == 0: raise ZeroDivisionError("xn - 1 == 0 (vanishing.rs:100)")
     expected_h = h_eval * pow(xn - 1, -1, R) % R
     h_msm = [(pow(xn, i, R), h_c[i]) for i in range(H - 1, -1, -1)]   # bases h_{H-1}..h_0
 
-    # queries (lib.rs:349-414); commitment identity = a hashable key
+    # queries (lib.rs:349-414); commitment identity = a hashable key (per-instance commitments carry the instance index)
     Q = []
-    for (col, _, r_), e in zip(vk["advice_queries"], adv_e): Q.append((("adv", col), rot(x, r_), e))
-    for i in range(nsets): Q.append((("pz", i), x, pz[i][0])); Q.append((("pz", i), rot(x, 1), pz[i][1]))
-    for i in range(nsets - 2, -1, -1): Q.append((("pz", i), rot(x, -(bf + 1)), pz[i][2]))
-    for i in range(L):
-        z, zn, a_, ai, s_ = lk_e[i]
-        Q += [(("lkz", i), x, z), (("lka", i), x, a_), (("lks", i), x, s_), (("lka", i), rot(x, -1), ai), (("lkz", i), rot(x, 1), zn)]
-    for i in range(Sh): Q += [(("shz", i), x, sh_e[i][0]), (("shz", i), rot(x, 1), sh_e[i][1])]
+    base = {("rand", 0): random_c}
+    for q in range(M):
+        for (col, _, r_), e in zip(vk["advice_queries"], adv_e[q]): Q.append((("adv", q, col), rot(x, r_), e))
+        for i in range(nsets): Q.append((("pz", q, i), x, pz[q][i][0])); Q.append((("pz", q, i), rot(x, 1), pz[q][i][1]))
+        for i in range(nsets - 2, -1, -1): Q.append((("pz", q, i), rot(x, -(bf + 1)), pz[q][i][2]))
+        for i in range(L):
+            z, zn, a_, ai, s_ = lk_e[q][i]
+            Q += [(("lkz", q, i), x, z), (("lka", q, i), x, a_), (("lks", q, i), x, s_), (("lka", q, i), rot(x, -1), ai), (("lkz", q, i), rot(x, 1), zn)]
+        for i in range(Sh): Q += [(("shz", q, i), x, sh_e[q][i][0]), (("shz", q, i), rot(x, 1), sh_e[q][i][1])]
+        for i in range(A): base[("adv", q, i)] = advice_c[q][i]
+        for i in range(nsets): base[("pz", q, i)] = perm_z[q][i]
+        for i in range(L): base[("lkz", q, i)] = lk_z[q][i]; base[("lka", q, i)] = lk_in[q][i]; base[("lks", q, i)] = lk_tab[q][i]
+        for i in range(Sh): base[("shz", q, i)] = sh_z[q][i]
     for (col, r_), e in zip(vk["fixed_queries"], fix_e): Q.append((("fix", col), rot(x, r_), e))
     for i in range(Pn): Q.append((("sig", i), x, sig_e[i]))
     Q.append((("hmsm", 0), x, expected_h))
     Q.append((("rand", 0), x, random_e))
-    base = {("rand", 0): random_c}
-    for i in range(A): base[("adv", i)] = advice_c[i]
-    for i in range(nsets): base[("pz", i)] = perm_z[i]
-    for i in range(L): base[("lkz", i)] = lk_z[i]; base[("lka", i)] = lk_in[i]; base[("lks", i)] = lk_tab[i]
-    for i in range(Sh): base[("shz", i)] = sh_z[i]
     for i, c in enumerate(vk["fixed_commitments"]): base[("fix", i)] = c
     for i, c in enumerate(vk["perm_commitments"]): base[("sig", i)] = c
 
@@ -561,10 +579,10 @@ def msm(terms):
     return acc
 
 
-def verify_single(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B):
+def verify_single(params, vk, instances, proof, multiopen=SHPLONK, transcript=BLAKE2B, circuit_instances=1):
     """SingleStrategy: 0 ok, -2 ConstraintSystemFailure, -5 Transcript, -4 Opening, -1 InvalidInstances, -7 panic"""
     try:
-        g = guard(params, vk, instances, proof, multiopen, transcript)
+        g = guard(params, vk, instances, proof, multiopen, transcript, circuit_instances)
     except ValueError as e:
         return {"transcript": -5, "opening": -4, "invalid_instances": -1}[e.args[1]]
     except ZeroDivisionError:

@@ -29,14 +29,17 @@ R = pyref.R
 def case(name, s, proofs, rand_seed, notes):
     params, vk = pyref.read_params_raw(s.params), pyref.read_vk_raw(s.vk)
     mo, trk = s.multiopen, s.transcript
+    M = getattr(s, "circuit_instances", 1)   # instances.len() of verify_proof (lib.rs:43): circuit instances per transcript
     out = dict(name=name, notes=notes, g1_flag_layout="byte31: bit7 identity, bit6 sign(y)", serde_format="RawBytes",
                multiopen=mo, transcript=trk, params=s.params.hex(), vk=s.vk.hex(), proofs=[])
+    if M != 1:
+        out["circuit_instances"] = M
     guards = []
     for label, proof, inst in proofs:
         insts = [[int.from_bytes(v, "little") for v in col] for col in inst]
         entry = dict(label=label, proof=proof.hex(), instances=[[v.hex() for v in col] for col in inst])
         try:
-            g = pyref.guard(params, vk, insts, proof, mo, trk)
+            g = pyref.guard(params, vk, insts, proof, mo, trk, M)
             entry["guard_status"] = 0
             entry["challenges"] = [c.to_bytes(32, "little").hex() for c in g["challenges"]]
             # the Guard term by term, in the order the reference appends them (shplonk.rs:256-264, gwc.rs:86-132)
@@ -48,7 +51,7 @@ def case(name, s, proofs, rand_seed, notes):
         except ValueError as e:
             entry["guard_status"] = {"transcript": -5, "opening": -4}[e.args[1]]
             guards.append(None)
-        entry["single_status"] = pyref.verify_single(params, vk, insts, proof, mo, trk)
+        entry["single_status"] = pyref.verify_single(params, vk, insts, proof, mo, trk, M)
         out["proofs"].append(entry)
     # AccumulatorStrategy over all proofs with seeded draws: acc = sum_i (prod_{j>i} r_j) msm_i  (kzg/strategy.rs:125-136)
     rnd = random.Random(rand_seed)
@@ -91,6 +94,29 @@ def main():
         s.free()
         if ONLY == {"wide_k16_lookup_heavy"}:
             return
+    # 7. several circuit instances per transcript (`instances.len() > 1`, lib.rs:43-55: interleaved reads :91-161, :220-253, one
+    #    expression / query block per instance :273-391) — no caller inside the reference passes more than one, so these fixtures
+    #    (two independent restatements agreeing) are all that pins M > 1
+    s = circuits.setup_vector_mul(8, 6).set_circuit_instances(2)
+    good, inst = circuits.prove_vector_mul_multi(s, 2, seed=41)
+    bad_inst = [list(c) for c in inst]; bad_inst[1][0] = circuits.le32(5)             # a public input of the SECOND instance
+    case("vector_mul_m2", s, [("valid", good, inst), ("second_instance_public_input", good, bad_inst)], 9,
+         "two circuit instances in one transcript (SHPLONK / Blake2b), 6 multiplications each; second entry: a wrong public input of instance 1")
+    s.free()
+    s = circuits.setup_wide(8, A=8, F=5, L_=1, Sh=1, deg=4).set_options(circuits.GWC, circuits.BLAKE2B).set_circuit_instances(2)
+    good, inst = circuits.prove_wide_multi(s, 2, witness_seed=12)
+    bad, inst_b = circuits.prove_wide_multi(s, 2, witness_seed=12, tamper_at=1)
+    case("wide_gwc_m2", s, [("valid", good, inst), ("lookup_violated_in_second_instance", bad, inst_b)], 10,
+         "two circuit instances in one transcript (GWC / Blake2b): 8 advice, 5 fixed, 1 lookup, 1 shuffle, degree 4; second proof violates the lookup of instance 1")
+    s.free()
+    s = circuits.setup_shuffle(8, 4, 32).set_options(circuits.SHPLONK, circuits.KECCAK256).set_circuit_instances(3)
+    good, inst = circuits.prove_shuffle_multi(s, 3, data_seed=8)
+    bad, _ = circuits.prove_shuffle_multi(s, 3, data_seed=8, break_at=2)
+    case("two_phase_shuffle_m3", s, [("valid", good, inst), ("broken_shuffle_in_third_instance", bad, inst)], 11,
+         "three circuit instances in one transcript (SHPLONK / Keccak-256), two-phase advice with user challenges; second proof: the shuffle of instance 2 is broken")
+    s.free()
+    if ONLY and ONLY <= {"vector_mul_m2", "wide_gwc_m2", "two_phase_shuffle_m3"}:
+        return
     # 1. the reference's vector_mul test (tests/vector_mul.rs:297-333) on the reference's own SRS file
     s = circuits.setup_vector_mul(8, 10, use_reference_srs=True)
     good, inst = circuits.prove_vector_mul(s, [2] * 10, [3] * 10, rng_seed=0)

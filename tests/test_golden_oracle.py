@@ -14,6 +14,11 @@ class _S:  # the subset of circuits.Setup the oracle helpers use
         self.L, self.params, self.vk = L, h(case["params"]), h(case["vk"])
         self.ninst_cols = len(case["proofs"][0]["instances"])
         self.multiopen, self.transcript = case.get("multiopen", 0), case.get("transcript", 0)
+        self.circuit_instances = case.get("circuit_instances", 1)
+
+    def use(self):
+        self.L.h2o_set_verify_options(self.multiopen, self.transcript)
+        self.L.h2o_set_circuit_instances(self.circuit_instances)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])

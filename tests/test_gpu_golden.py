@@ -13,7 +13,7 @@ CASES = golden_util.cases()
 def test_gpu_matches_golden(case):
     import halo2_verifier_amd as h2v
     ctx = h2v.Context(h2v.ParamsKZG(h(case["params"]), h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(h(case["vk"]), h2v.SerdeFormat.RawBytes),
-                      multiopen=case.get("multiopen", 0), transcript=case.get("transcript", 0))
+                      multiopen=case.get("multiopen", 0), transcript=case.get("transcript", 0), circuit_instances=case.get("circuit_instances", 1))
     proofs, insts = [], []
     for e in case["proofs"]:
         proof, inst = h(e["proof"]), golden_util.instances_of(e)
