@@ -200,7 +200,7 @@ def traffic_record(terms_per_launch):
             continue
         if not t or not b:
             continue
-        key = (abs(t - terms_per_launch), -os.path.getmtime(path))
+        key = (abs(t - terms_per_launch), [-ord(c) for c in os.path.basename(path)])   # same shape: the latest round's file (names sort by round; mtimes do not survive a checkout)
         if best is None or key < best[0]:
             best = (key, path, t, b, tj)
     if best is None:
@@ -513,7 +513,8 @@ def rank_main(args):
         acc_ms = src.get("msm_accumulate", 0.0)
         valu = None
         try:
-            valu = (tj or {}).get("valu_active", {}).get("h2v::msm_accumulate")
+            va = (tj or {}).get("valu_active", {})
+            valu = next((v for k2, v in va.items() if k2 == "h2v::msm_accumulate" or k2.startswith("h2v::msm_accumulate<")), None)
         except Exception:
             pass
         kernels = {"msm_accumulate": {"ms": acc_ms, "ms_timed_region": stages.get("msm_accumulate", 0.0),

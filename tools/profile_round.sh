@@ -15,16 +15,17 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$GRAFT_REPO_ROOT/bench.py"
 DRV="--gpus 1 --steps 20 --warmup 5"
-LEAN="--no-cpu-baseline --no-reupload-leg"
+LEAN="--no-cpu-baseline --no-reupload-leg --no-extra-legs"
 D1="--steps 128 --warmup 32 --depth 1 $LEAN"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/driver" -o k --output-format csv -- python3 "$B" $DRV > "$OUT/driver.json" 2> "$OUT/driver.err"
-timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/default" -o k --output-format csv -- python3 "$B" --no-cpu-baseline > "$OUT/default.json" 2> "$OUT/default.err"
+timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/default" -o k --output-format csv -- python3 "$B" --no-cpu-baseline --no-extra-legs > "$OUT/default.json" 2> "$OUT/default.err"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$OUT/drv_fetch" -o k --output-format csv -- python3 "$B" $DRV $LEAN > "$OUT/drv_fetch.json" 2> "$OUT/drv_fetch.err"
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$OUT/drv_write" -o k --output-format csv -- python3 "$B" $DRV $LEAN > "$OUT/drv_write.json" 2> "$OUT/drv_write.err"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY -d "$OUT/drv_valu" -o k --output-format csv -- python3 "$B" $DRV $LEAN > "$OUT/drv_valu.json" 2> "$OUT/drv_valu.err"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$OUT/d1_fetch" -o k --output-format csv -- python3 "$B" $D1 > "$OUT/d1_fetch.json" 2> "$OUT/d1_fetch.err"
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$OUT/d1_write" -o k --output-format csv -- python3 "$B" $D1 > "$OUT/d1_write.json" 2> "$OUT/d1_write.err"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY -d "$OUT/d1_valu" -o k --output-format csv -- python3 "$B" $D1 > "$OUT/d1_valu.json" 2> "$OUT/d1_valu.err"
-# the raw per-dispatch traces are large: keep the stats and the counter tables only
-find "$OUT" -name "*kernel_trace.csv" -delete
+# the raw per-dispatch traces are large: keep the stats and the counter tables — and the driver command's trace (a few thousand rows),
+# from which summarize_profiles.py takes the headline launches alone (the command also runs legs on other VKs under the same kernel names)
+find "$OUT" -name "*kernel_trace.csv" -not -path "*/driver/*" -delete
 ls -R "$OUT" | head -60

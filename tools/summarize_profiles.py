@@ -75,12 +75,48 @@ def counters(sub):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
+def headline_stats(sub, dst, header):
+    """Per-kernel averages over the HEADLINE launches of the driver command only.  The command also runs the PCIe-inclusive leg (same
+    launch shape: kept), the config-4 leg (another VK, launches in flight) and the SingleStrategy leg (512 one-proof groups) under the
+    same kernel names; a launch is the run of dispatches from one k_decompress to the next, and it counts when its k_decompress has the
+    grid of the very first one (the warm-up launch of the headline)."""
+    f = find(sub, "k_kernel_trace.csv")
+    if not f:
+        return {}
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    gkey = next(k for k in ("Grid_Size_X", "Grid_Size", "Workgroup_Count_X") if k in rows[0])
+    dec = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).endswith("k_decompress")]
+    if not dec:
+        return {}
+    want = rows[dec[0]][gkey]
+    acc = defaultdict(lambda: [0.0, 0])
+    launches = 0
+    for a, b in zip(dec, dec[1:] + [len(rows)]):
+        if rows[a][gkey] != want:
+            continue
+        launches += 1
+        for r in rows[a:b]:
+            k = r["Kernel_Name"]
+            acc[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); acc[k][1] += 1
+    with open(os.path.join(out, dst), "w") as o:
+        for h in header + [f"averages over the {launches} launches of the headline shape (k_decompress grid {want}); the all-legs table of rocprofv3 --stats is in {dst.replace('.csv', '_all_legs.csv')}"]:
+            o.write("# " + h + "\n")
+        o.write("Name,Calls,TotalDurationNs,AverageNs\n")
+        for k, (t, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+            o.write('"%s",%d,%d,%.1f\n' % (k, n, t, t / n))
+    return {short(k): t / n for k, (t, n) in acc.items()}
+
+
 bdrv, bdef = bench_line("driver.json"), bench_line("default.json")
-avg_drv = stats("driver", f"{tag}_kernel_stats_driver_cmd.csv",
+avg_all = stats("driver", f"{tag}_kernel_stats_driver_cmd_all_legs.csv",
                 ["rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5   (the command the driver runs; MI355X)",
                  "%s" % bdrv.get("config", {}).get("workload", ""),
-                 "calls: 1 warm-up + 1 timed launch + 4 launches re-timed alone after the timed region (+ 2 of the PCIe-inclusive leg); every launch carries 20 steps",
+                 "calls: 1 warm-up + 7 timed launches (the timed region repeated, median reported) + 4 launches re-timed alone after the timed region, the same again for the PCIe-inclusive leg, + the config-4 and SingleStrategy legs; every headline launch carries 20 steps",
                  "bench line of this run: value=%.0f proofs/s, ms_per_step=%.4f, stages_ms_one_launch_in_flight=%s" % (bdrv.get("value", 0), bdrv.get("ms_per_step", 0), json.dumps(bdrv.get("stages_ms_one_launch_in_flight", {})))])
+avg_drv = headline_stats("driver", f"{tag}_kernel_stats_driver_cmd.csv",
+                         ["rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5   (the command the driver runs; MI355X)",
+                          "%s" % bdrv.get("config", {}).get("workload", ""),
+                          "bench line of this run: value=%.0f proofs/s, ms_per_step=%.4f, stages_ms_one_launch_in_flight=%s" % (bdrv.get("value", 0), bdrv.get("ms_per_step", 0), json.dumps(bdrv.get("stages_ms_one_launch_in_flight", {})))]) or avg_all
 stats("default", f"{tag}_kernel_stats_default_cmd.csv",
       ["rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (the default bench command: 32 steps per launch, 8 launches in flight; MI355X)",
        "%s" % bdef.get("config", {}).get("workload", ""),
