@@ -50,6 +50,20 @@ int main(int argc, char** argv) {
         printf("batch %d ", ok ? 1 : 0); hex(acc.left(), 64); printf(" "); hex(acc.right(), 64);
         for (int s : acc.statuses()) printf(" %d", s);
         printf("\n");
+        // AccumulatorStrategy::with(msm_accumulator) (kzg/strategy.rs:75-78): the first half accumulated, its evaluated channels
+        // resumed as the seed of the second half — must equal the one accumulation above
+        const size_t half = n / 2;
+        AccumulatorStrategy first(params);
+        first.set_randomness(Bytes(rand.begin(), rand.begin() + 32 * half));
+        for (size_t i = 0; i < half; ++i) verify_proof(params, vk, first, inst_of(i), proof_of(i));
+        const bool ok1 = first.finalize();
+        Bytes one(32, 0); one[0] = 1;
+        AccumulatorStrategy second = AccumulatorStrategy::with(params, one, Bytes(first.left(), first.left() + 64), one, Bytes(first.right(), first.right() + 64));
+        second.set_randomness(Bytes(rand.begin() + 32 * half, rand.end()));
+        for (size_t i = half; i < n; ++i) verify_proof(params, vk, second, inst_of(i), proof_of(i));
+        const bool ok2 = second.finalize();
+        printf("resumed %d ", (ok1 && ok2) ? 1 : 0); hex(second.left(), 64); printf(" "); hex(second.right(), 64);
+        printf("\n");
     } catch (const Failure& e) {
         printf("failure %d %s\n", e.code, e.what());
         return 1;

@@ -45,4 +45,8 @@ def test_cpp_harness_matches_oracle(tmp_path):
     ok, st, left, right = circuits.oracle_verify_batch(s, P, I, rand)
     assert (b[1] == "1") == ok and bytes.fromhex(b[2]) == left and bytes.fromhex(b[3]) == right and [int(x) for x in b[4:]] == st
     assert ok is False
+    # AccumulatorStrategy::with: the accumulation resumed from its first half gives the same two points (the verdict differs only
+    # through proof 2's failing pairing, which both see)
+    r = [l for l in out if l.startswith("resumed ")][0].split()
+    assert bytes.fromhex(r[2]) == left and bytes.fromhex(r[3]) == right and r[1] == "0"
     s.free()

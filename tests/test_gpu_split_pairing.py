@@ -132,7 +132,7 @@ def test_gwc_plan_has_its_own_shift():
 @pytest.mark.parametrize("knobs", [dict(pairing_one_stream=1), dict(frvm_streams=1), dict(pairing_one_stream=1, frvm_streams=1), dict(frvm_streams=2), dict(frvm_streams=3),
                                    dict(frvm_streams=2, frvm_lds_kb=36), dict(frvm_streams=4, frvm_lds_kb=78), dict(msm_global_sort=1), dict(msm_parts=1, frvm_streams=1),
                                    dict(msm_window_threads=64, msm_window_slots=3), dict(msm_window_threads=64, msm_window_wpw=2), dict(msm_window_threads=128, msm_window_wpw=2),
-                                   dict(msm_window_threads=256)])
+                                   dict(msm_window_threads=256), dict(msm_acc_waves=4), dict(msm_acc_waves=4, msm_global_sort=1)])
 def test_single_stream_and_fallback_kernels_stay_exact(pool, knobs):
     """The default path runs the Fr program and the pairing as two instruction streams each and sorts inside LDS; the single-stream
     interpreter, the single-stream pairing table over merged lines, the whole-point pairing and the global counting sort remain in
