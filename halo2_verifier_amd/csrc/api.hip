@@ -50,14 +50,14 @@ int h2v_ctx_set_tuning(h2v_ctx* ctx, const h2v_tuning* t) {
     Tuning n;
     if (t) {
         if (t->struct_size != sizeof(h2v_tuning)) { set_last_error("h2v_ctx_set_tuning: h2v_tuning.struct_size does not match this library"); return H2V_ERR_BAD_ARGUMENT; }
-        const int vals[] = {t->frvm_streams, t->frvm_lds_kb, t->msm_parts, t->msm_global_sort, t->msm_no_term_split, t->msm_window_threads, t->msm_window_wpw, t->msm_window_slots, t->msm_acc_waves, t->pairing_one_stream};
+        const int vals[] = {t->frvm_streams, t->frvm_lds_kb, t->msm_parts, t->msm_global_sort, t->msm_no_term_split, t->msm_window_threads, t->msm_window_wpw, t->msm_window_slots, t->msm_acc_waves, t->pairing_one_stream, t->upload_mode};
         for (int v : vals) if (v < 0) { set_last_error("h2v_ctx_set_tuning: negative field"); return H2V_ERR_BAD_ARGUMENT; }
         if (t->frvm_streams > 4 || t->msm_parts > MSM_MAX_PARTS || (t->msm_window_threads && t->msm_window_threads != 64 && t->msm_window_threads != 128 && t->msm_window_threads != 256) ||
-            (t->msm_window_wpw && t->msm_window_wpw != 1 && t->msm_window_wpw != 2 && t->msm_window_wpw != 4) || (t->msm_window_slots && t->msm_window_slots != 3 && t->msm_window_slots != 5) || (t->msm_acc_waves && t->msm_acc_waves != 3 && t->msm_acc_waves != 4)) {
+            (t->msm_window_wpw && t->msm_window_wpw != 1 && t->msm_window_wpw != 2 && t->msm_window_wpw != 4) || (t->msm_window_slots && t->msm_window_slots != 3 && t->msm_window_slots != 5) || (t->msm_acc_waves && t->msm_acc_waves != 3 && t->msm_acc_waves != 4) || t->upload_mode > 3) {
             set_last_error("h2v_ctx_set_tuning: value out of range (see h2v.h)"); return H2V_ERR_BAD_ARGUMENT;
         }
         n.frvm_streams = t->frvm_streams; n.frvm_lds_kb = t->frvm_lds_kb; n.msm_parts = t->msm_parts; n.msm_global_sort = t->msm_global_sort; n.msm_no_term_split = t->msm_no_term_split;
-        n.msm_window_threads = t->msm_window_threads; n.msm_window_wpw = t->msm_window_wpw; n.msm_window_slots = t->msm_window_slots; n.msm_acc_waves = t->msm_acc_waves; n.pairing_one_stream = t->pairing_one_stream;
+        n.msm_window_threads = t->msm_window_threads; n.msm_window_wpw = t->msm_window_wpw; n.msm_window_slots = t->msm_window_slots; n.msm_acc_waves = t->msm_acc_waves; n.pairing_one_stream = t->pairing_one_stream; n.upload_mode = t->upload_mode;
     }
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->tuning = n;

@@ -152,13 +152,35 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     }
     size_t point_bytes = 0;
     for (auto& r : runs) point_bytes += r.second;
-    if (runs.size() > 4 || 2 * point_bytes > pl.proof_len) {   // points all over the proof, or most of it: nothing to gain
+    int mode = ctx->tuning.upload_mode;
+    if (mode == 0) mode = 1;   // (tools/r03_upload_modes.sh: in the benchmark's loop the three forms are within its noise, 0.873 / 0.875 / 0.878 of the resident rate;
+                               //  called once, tools/h2d_probe.py: 3.35 ms points-first against 3.60 ms plain)
+    if (mode == 1 && (runs.size() > 4 || 2 * point_bytes > pl.proof_len)) mode = 3;   // points all over the proof, or most of it: nothing to gain
+    if (n < 2048) mode = 3;                                                           // a copy of a megabyte or two is not worth two launches
+    if (mode == 3) {
         if ((rc = copy_proofs(s, 0, n)) || (rc = copy_rest(s))) return rc;
         H2V_HIP_CHECK(hipStreamSynchronize(s));
         return 0;
     }
     if (!b->copy) H2V_HIP_CHECK(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
     H2V_HIP_CHECK(hipStreamSynchronize(s));   // an earlier launch of this batch may still read the buffers (normally long finished: h2v_batch_finish)
+    if (mode == 2) {
+        // the proofs in two halves: [first half] -> its decompression is enqueued -> [second half, instances, draws] travel while the GPU
+        // decompresses the first -> the second half's decompression.  Two rounds of the decompression kernel at half occupancy take about
+        // what one round at full occupancy takes, and the second copy hides behind the first round.
+        StageArgs g{(uint32_t)n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};
+        if ((rc = decompress_begin_enqueue(s, g))) return rc;
+        const size_t half = (n / 2 + 15) / 16 * 16;
+        if ((rc = copy_proofs(b->copy, 0, half))) return rc;
+        H2V_HIP_CHECK(hipStreamSynchronize(b->copy));
+        if ((rc = decompress_range_enqueue(s, g, 0, (uint32_t)half))) return rc;
+        if ((rc = copy_proofs(b->copy, half, n)) || (rc = copy_rest(b->copy))) return rc;
+        H2V_HIP_CHECK(hipStreamSynchronize(b->copy));   // everything is on the device; the host buffers are the caller's again
+        if ((rc = decompress_range_enqueue(s, g, (uint32_t)half, (uint32_t)n))) return rc;
+        if ((rc = decompress_finish_enqueue(s, g))) return rc;
+        b->decompressed = true;
+        return 0;
+    }
     for (auto& r : runs) H2V_HIP_CHECK(hipMemcpy2DAsync(b->proofs + r.first, pl.proof_len, proofs_flat + r.first, proof_len, r.second, n, hipMemcpyHostToDevice, b->copy));
     H2V_HIP_CHECK(hipStreamSynchronize(b->copy));
     StageArgs g{(uint32_t)n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};

@@ -38,6 +38,7 @@ struct Tuning {
     int frvm_streams = 0, frvm_lds_kb = 0;
     int msm_parts = 0, msm_global_sort = 0, msm_no_term_split = 0, msm_window_threads = 0, msm_window_wpw = 0, msm_window_slots = 0, msm_acc_waves = 0;
     int pairing_one_stream = 0;
+    int upload_mode = 0;
 };
 
 // ------------------------------------------------------------------ MSM (msm.hip)

@@ -52,7 +52,7 @@ class _Options(ctypes.Structure):   # h2v_options
 class _Tuning(ctypes.Structure):    # h2v_tuning (debug / test): forced kernel variants, 0 = automatic
     _fields_ = [("struct_size", ctypes.c_size_t)] + [(k, ctypes.c_int) for k in (
         "frvm_streams", "frvm_lds_kb", "msm_parts", "msm_global_sort", "msm_no_term_split", "msm_window_threads", "msm_window_wpw",
-        "msm_window_slots", "msm_acc_waves", "pairing_one_stream")]
+        "msm_window_slots", "msm_acc_waves", "pairing_one_stream", "upload_mode")]
 
 
 class ParamsKZG:

@@ -110,12 +110,16 @@ int h2v_ctx_create_ex(const uint8_t* params, size_t params_len, int params_forma
  *   msm_window_wpw      windows per workgroup of the window reduction (1, 2, 4)
  *   msm_window_slots    3: the 20 KB form of the window reduction without the two-bit digit table (automatic: beyond 1024 windows)
  *   msm_acc_waves       3 or 4: waves per SIMD msm_accumulate is compiled for (automatic: 3 — 156 registers, no spills)
- *   pairing_one_stream  1: the single-stream pairing table over split accumulators instead of the two-stream one */
+ *   pairing_one_stream  1: the single-stream pairing table over split accumulators instead of the two-stream one
+ *   upload_mode         h2v_batch_upload_launch: 1 = point bytes first, then one decompression launch under the full copy;
+ *                       2 = the proofs in two halves, each decompressed as soon as it has arrived; 3 = plain upload, then launch
+ *                       (automatic: see the function) */
 typedef struct h2v_tuning {
     size_t struct_size;
     int frvm_streams, frvm_lds_kb;
     int msm_parts, msm_global_sort, msm_no_term_split, msm_window_threads, msm_window_wpw, msm_window_slots, msm_acc_waves;
     int pairing_one_stream;
+    int upload_mode;
 } h2v_tuning;
 int h2v_ctx_set_tuning(h2v_ctx* ctx, const h2v_tuning* tuning);
 void h2v_ctx_destroy(h2v_ctx* ctx);

@@ -14,7 +14,7 @@ use core::ffi::{c_char, c_float, c_int, c_void};
 /// debug / test: forced kernel variants, every field 0 = automatic (h2v_ctx_set_tuning)
 #[repr(C)] pub struct h2v_tuning { pub struct_size: usize, pub frvm_streams: c_int, pub frvm_lds_kb: c_int, pub msm_parts: c_int, pub msm_global_sort: c_int,
                                    pub msm_no_term_split: c_int, pub msm_window_threads: c_int, pub msm_window_wpw: c_int, pub msm_window_slots: c_int,
-                                   pub msm_acc_waves: c_int, pub pairing_one_stream: c_int }
+                                   pub msm_acc_waves: c_int, pub pairing_one_stream: c_int, pub upload_mode: c_int }
 pub const H2V_ABI_VERSION: c_int = 3;
 pub const H2V_VK_LAYOUT_WRITER: c_int = 0;
 pub const H2V_VK_LAYOUT_READER: c_int = 1;
