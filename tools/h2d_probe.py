@@ -19,6 +19,10 @@ print("launch+finish (resident)        %.3f ms" % t(lambda: (b.launch(True), b.f
 print("upload only                     %.3f ms" % t(lambda: b.upload(proofs, 1024, inst, [8], tail)))
 print("upload + launch + finish        %.3f ms" % t(lambda: (b.upload(proofs, 1024, inst, [8], tail), b.launch(True), b.finish_groups(raw_statuses=True))))
 print("upload_launch (returns)         %.3f ms" % t(lambda: (b.upload_launch(proofs, 1024, inst, [8], tail), b.finish_groups(raw_statuses=True))[0] if False else (b.upload_launch(proofs, 1024, inst, [8], tail), b.finish_groups(raw_statuses=True))))
+for mode in (1, 2, 3):
+    ctx.set_tuning(upload_mode=mode)
+    print("upload_launch + finish, mode %d      %.3f ms" % (mode, t(lambda: (b.upload_launch(proofs, 1024, inst, [8], tail), b.finish_groups(raw_statuses=True)), 15)))
+ctx.set_tuning()
 def ul():
     t0 = time.perf_counter(); b.upload_launch(proofs, 1024, inst, [8], tail); t1 = time.perf_counter(); b.finish_groups(raw_statuses=True); t2 = time.perf_counter()
     return (t1 - t0) * 1e3, (t2 - t1) * 1e3

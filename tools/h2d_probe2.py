@@ -9,6 +9,8 @@ proofs = d["proofs"] * G; inst = d["inst"] * G
 tail = b"".join(((i * 0x9e3779b97f4a7c15 + 0x1234567) % (1 << 250)).to_bytes(32, "little") for i in range(1, 1024 * G + 1))
 b = h2v.Batch(ctx, 1024 * G, 8, groups=G)
 mode = sys.argv[1]
+if len(sys.argv) > 2:
+    ctx.set_tuning(upload_mode=int(sys.argv[2]))
 for _ in range(4):
     if mode == "overlap":
         b.upload_launch(proofs, 1024, inst, [8], tail)
