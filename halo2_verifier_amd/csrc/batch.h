@@ -87,7 +87,6 @@ int frvm_enqueue(hipStream_t s, const FrvmArgs& a, uint32_t n_slots);
 int fold_shared_enqueue(hipStream_t s, const Fr* d_shared, uint32_t n, uint32_t np, uint32_t n_shared, uint32_t groups, uint32_t* d_msm_scal);
 }  // namespace h2v
 
-#define H2V_UPLOAD_CHUNKS 8
 struct h2v_batch {
     h2v_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;

@@ -115,7 +115,7 @@ MsmPlan msm_plan(uint32_t n, bool latency) {
 static inline bool msm_latency_bound(size_t total_terms) { return total_terms <= 4096; }
 
 // Large problems are cut into sub-problems of at most MSM_LDS_SORT_MAX_TERMS terms (msm_enqueue_multi): the workspace is sized for the
-// sub-problems, and for the uncut form too (knob H2V_MSM_NO_TERM_SPLIT).
+// sub-problems, and for the uncut form too (h2v_tuning.msm_no_term_split).
 static inline uint32_t msm_subproblems(uint32_t n) { return n > MSM_LDS_SORT_MAX_TERMS ? (n + MSM_LDS_SORT_MAX_TERMS - 1) / MSM_LDS_SORT_MAX_TERMS : 1u; }
 int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_per_problem) {
     release();
@@ -713,6 +713,9 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
 // Buckets that run over a few chunks (the top window's: a 7-bit digit, a few dozen buckets that take 1/64 of the entries each) are
 // rare but scattered through the list: one lane per bucket, every second wave had one of them and waited for its 8 .. 16 sequential
 // additions (0.13 - 0.45 ms for 0.03 ms of arithmetic).  They are summed by teams of eight lanes in the first workgroups of the launch.
+// (Round 3 tried the teams as a kernel of their own — with their calls inside, msm_fixup is compiled for 280 + 32 registers where the
+// lane path alone needs 113: the lane kernel then takes 48 us instead of sharing 77, but the team kernel is a 70 us chain of its own
+// and the two run one after the other: 118 us.  Inside one launch the lane path hides under the teams' chain.)
 __device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                             const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, const MsmSeg& g) {
     const uint32_t n_team = counts[nb + 3], r = threadIdx.x & 7u;
@@ -1081,7 +1084,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     g = MsmSeg{ws.seg_start, 1, nb, 0, lanes_round};
     }
     // one lane per chunk of the sorted list; the entry count is only known on the device, the grid covers the host's bound on it.
-    // Surplus workgroups are not free: the kernel holds exactly its occupancy in working workgroups (2 waves per SIMD), so the
+    // Surplus workgroups are not free: the kernel holds exactly its occupancy in working workgroups (3 waves per SIMD), so the
     // surplus is dispatched after they retire, ~7 ns each — the old bound (every term non-zero, shortest chunk) cost 9 500 empty
     // workgroups, 0.07 ms, at the end of every 20-step launch.
     const uint32_t acc_blocks = msm_accumulate_blocks(total_nz * 2 * p.windows, lanes_round);

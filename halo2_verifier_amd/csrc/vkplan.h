@@ -112,7 +112,7 @@ struct Plan {
     // instance shape this plan was compiled for
     std::vector<size_t> col_lens;
     uint32_t n_instance_values = 0;
-    // Wide instance vectors (more than H2V_WIDE_INSTANCES values): sum_j inst[j] * l_{j-rot}(x) (lib.rs:173-218) is not unrolled
+    // Wide instance vectors (more than 1024 values; h2v_options.instance_kernel_threshold): sum_j inst[j] * l_{j-rot}(x) (lib.rs:173-218) is not unrolled
     // into the Fr program (9 instructions and a slot per public input) but evaluated by k_instance_eval, one workgroup per proof
     struct InstQuery { uint32_t base, len; Fr w_start; };   // flat offset / length of the column, omega^(-rotation)
     bool wide_instances = false;

@@ -403,7 +403,7 @@ struct Builder {
             // the ready node with the longest tail; the stream where it finishes first
             size_t best = 0;
             for (size_t r = 1; r < ready.size(); ++r) if (bl[ready[r]] > bl[ready[best]] + 1e-9) best = r;
-            // (knob H2V_FRVM_SLACK > 0: within that slack of the longest tail a consumer of the node scheduled last goes first — fewer live slots,
+            // (SLACK > 0: within that slack of the longest tail a consumer of the node scheduled last goes first — fewer live slots,
             // but measured slower with four streams: 213 / 230 / 254 us for a slack of 0 / 1 / 3 products; the default is 0)
             if (last_node != (Val)-1) {
                 const double top = bl[ready[best]];
