@@ -131,6 +131,11 @@ bool vk_from_bytes(const uint8_t* data, size_t len, int fmt, VkHost& vk, std::st
     if (!read_fr(r, fmt, vk.transcript_repr, err)) return false;
     if (!r.ok) { err = "failed to fill whole buffer"; return false; }
     if (vk.cs_degree < 3) { err = "cs_degree below the permutation argument's minimum of 3"; return false; }
+    // VerifyingKey::read builds EvaluationDomain::new(cs_degree, k), which asserts that the extended domain 2^k (cs_degree - 1) fits the
+    // 2-adicity of Fr (poly/domain.rs:44-50: extended_k <= S = 28).  cs_degree is the one count of the format that consumes no bytes,
+    // so nothing else bounds it (found by fuzzing the parser under AddressSanitizer: a flipped bit made the plan compiler lay out
+    // 2^31 quotient commitments).
+    if (((uint64_t)(vk.cs_degree - 1) << vk.k) > (1ull << 28)) { err = "cs_degree: the extended domain exceeds the 2-adicity of Fr (EvaluationDomain::new asserts extended_k <= 28)"; return false; }
     return true;
 }
 
@@ -597,6 +602,13 @@ int compile_plan(const VkHost& vk, const ParamsHost& params, const std::vector<s
     };
     auto norm_rot = [&](int64_t r) { int64_t m = (int64_t)n; return ((r % m) + m) % m; };
 
+    // a proof of this VK: Np points, Ns scalars.  The layout tables below are linear in them; a key that asks for more
+    // than 2^16 of either is refused rather than laid out (real keys: tens to hundreds)
+    {
+        const uint64_t np_total = (uint64_t)M * (A + 3 * L + Sh + nsets) + 1 + H + 2 + 64;
+        const uint64_t ns_total = (uint64_t)M * (Qa + 3 * nsets + 5 * L + 2 * Sh) + Qf + 1 + P;
+        if (np_total > 65536 || ns_total > 65536) { err = "a proof of this VerifyingKey has more than 65536 points or scalars: not supported by this build"; return H2V_ERR_UNSUPPORTED; }
+    }
     // ---------------- proof layout + transcript stream
     // point slots; the per-instance ones are indexed [m * count + i]
     std::vector<uint32_t> advice_slot(M * A, 0), lk_input_slot(M * L), lk_table_slot(M * L), lk_product_slot(M * L), sh_slot(M * Sh), perm_slot(M * nsets), h_slot(H);
