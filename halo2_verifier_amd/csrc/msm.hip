@@ -821,6 +821,9 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
         // of the 64 had a one at every position, so the wave paid a doubling AND an addition per bit of its largest lo (10 of each at
         // T = 128) whatever the lanes' own bit counts (a non-adjacent form changed nothing, measured); two-bit digits are 5 additions
         // and 10 doublings for every lane alike.  (Measured without this phase: 0.255 of the kernel's 0.35 ms.)
+        // (Round 3 replaced it by a suffix scan of the slice totals across the lanes — sum_t t run_t = sum_{t >= 1} sum_{u >= t} run_u:
+        // 7 additions + 3 doublings + 1 addition per lane instead of 5 additions + 10 doublings — and measured no change, 0.34 - 0.37 ms
+        // either way: a doubling is half an addition, and the scan needs eight workgroup barriers.  Not kept.)
         G1J* run2 = mine + 3 * T + t;
         G1J* run3 = mine + 4 * T + t;
         if (lo < hi && t > 0) {
