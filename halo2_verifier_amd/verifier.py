@@ -185,6 +185,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for b in list(getattr(self, "_batches", ())):   # h2v_ctx_destroy: the context's batches go first
+                b.close()
             self._lib.h2v_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -443,6 +445,10 @@ class Batch:
         self.ctx, self._lib = ctx, ctx._lib
         self._h = ctypes.c_void_p()
         check(self._lib.h2v_batch_create(ctx._h, max_proofs, max_instance_values, ctypes.byref(self._h)))
+        if not hasattr(ctx, "_batches"):
+            import weakref
+            ctx._batches = weakref.WeakSet()
+        ctx._batches.add(self)
         self.max_proofs = max_proofs
         self.n = 0
         self.groups = 1

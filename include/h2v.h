@@ -122,6 +122,7 @@ typedef struct h2v_tuning {
     int upload_mode;
 } h2v_tuning;
 int h2v_ctx_set_tuning(h2v_ctx* ctx, const h2v_tuning* tuning);
+/* Destroys the context and everything compiled for it.  Every h2v_batch created on it must have been destroyed before. */
 void h2v_ctx_destroy(h2v_ctx* ctx);
 
 /* Re-serialisation of a VerifyingKey / ParamsKZG in another SerdeFormat — host only, no device needed:
