@@ -399,7 +399,7 @@ def rank_main(args):
         # N > 1 it runs shard -> export -> RCCL all-gather of G x 1312 B per rank -> fold -> ONE pairing per step
         shards, batches = [], []
         for s, g in zip(streams, sizes):
-            sb = h2d.ShardedBatch(ctx, B * g, N_PUBLIC, groups=g, stream=s.cuda_stream, device=dev,
+            sb = h2d.ShardedBatch(ctx, B * g, N_PUBLIC, groups=g, stream=s, device=dev,
                                   always_exchange=bool(os.environ.get("H2V_BENCH_FORCE_SHARDED")))   # (the knob runs the N > 1 call sequence on one GPU: what sharding costs besides the collective)
             sb.upload(proofs_one * g, 1024, inst_one * g, [N_PUBLIC], b"".join(tails[:g]))   # resident in HBM before the timed region
             sb.batch.set_profiling(h2v.Batch.PROFILE_KERNEL)   # timed region: only the dominant kernel's own timestamps (stage events are barrier packets)

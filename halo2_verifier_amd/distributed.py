@@ -119,6 +119,8 @@ class ShardedBatch:
     accumulators -> their records -> all-gather over the group -> fold -> ONE pairing per group; finish() returns what every rank
     agrees on.  With a world of one the launch simply ends in its own pairing.
 
+    stream: a torch.cuda.Stream (or a raw HIP stream handle) the batch runs on — collectives are issued under the same stream, so MSM,
+    all-gather and pairing are ordered without host synchronisation; None: a stream of the batch's own.
     batch_factory(ctx, max_proofs, max_instance_values, stream, groups) builds the object that runs a shard; the default is the
     HIP batch (verifier.Batch) — there is no CPU path in the product (the non-GPU test suite injects a stand-in to exercise the
     orchestration over gloo)."""
@@ -138,6 +140,9 @@ class ShardedBatch:
                 device = f"cuda:{ctx.device}"
         self.device = torch.device(device if device is not None else "cpu")
         self._torch_stream = None
+        if stream is not None and hasattr(stream, "cuda_stream"):   # a torch.cuda.Stream: collectives are issued under it as it is
+            self._torch_stream = stream
+            stream = stream.cuda_stream
         if stream is None and self.device.type == "cuda" and self.world > 1 and world_size is None:
             # the collective must be ordered with the batch's kernels: run both on one torch stream
             self._torch_stream = torch.cuda.Stream(device=self.device)
