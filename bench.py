@@ -14,8 +14,8 @@ steps start and finish inside the timed region.
 child processes, the parent never touches the GPU); under torch.distributed.run the ranks come from the environment.  Either
 way WORLD_SIZE must equal --gpus, otherwise the run fails instead of silently measuring another job.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the MSM stage (the kernel BASELINE.json names): achieved = 96 B x terms /
-mean MSM-stage time measured with HIP events on the batch's own stream; `roofline.kernels` breaks out msm_accumulate.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the MSM (msm_accumulate): achieved = 96 B x the terms of a
+launch / the kernel's average duration inside the timed region (its dispatch's own timestamps); `roofline.stage` has the whole MSM stage.
 `cpu_baseline` = the CPU oracle (a port of the reference algorithm, single thread like the reference) timed on a bounded
 sample of the same proofs on this host.
 """
@@ -517,8 +517,19 @@ def rank_main(args):
             valu = next((v for k2, v in va.items() if k2 == "h2v::msm_accumulate" or k2.startswith("h2v::msm_accumulate<")), None)
         except Exception:
             pass
+        acc_timed = stages.get("msm_accumulate", 0.0) or acc_ms          # the dispatch's own timestamps, every launch of the timed region
+        # HBM traffic of the dominant kernel alone, from the same committed PMC record (scaled per term when the shape differs)
+        acc_traffic = None
+        try:
+            pk = (tj or {}).get("per_kernel_bytes", {})
+            kb = next((v for k2, v in pk.items() if k2 == "h2v::msm_accumulate" or k2.startswith("h2v::msm_accumulate<")), None)
+            if kb is not None and tj.get("terms_per_launch"):
+                acc_traffic = kb * terms_total / tj["terms_per_launch"]
+        except Exception:
+            pass
+        acc_gbps = (96.0 * terms_total) / (acc_timed * 1e-3) / 1e9 if acc_timed > 0 else 0.0
         kernels = {"msm_accumulate": {"ms": acc_ms, "ms_timed_region": stages.get("msm_accumulate", 0.0),
-                                      "timing": "the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL events), every launch of the timed region", "alg_GBps": (96.0 * terms_total) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None,
+                                      "timing": "the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL events), every launch of the timed region; `ms` = the same for launches re-timed one at a time", "alg_GBps": (96.0 * terms_total) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else None,
                                       "valu_active": valu, "valu_active_source": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the committed --pmc pass named in traffic_source",
                                       "alu_frac": (2 * 12 * 11 * terms_total) / (acc_ms * 1e-3) / 168e9 if acc_ms > 0 else None,
                                       "alu_frac_note": "Fq products/s of the kernel (11 per mixed addition, 2 x 12 additions per term) over the measured chip-wide peak of the Montgomery product, 168 G/s (tools/limb29_microbench.hip)"}}
@@ -545,12 +556,18 @@ def rank_main(args):
             "config": {"workload": workload,
                        "inputs": "copied host -> device before every launch (PCIe-inclusive)" if args.reupload else "resident in HBM before the timed region",
                        "proofs_per_gpu_per_step": B, "steps_per_launch": G, "pipeline_depth": depth, "proof_bytes": shape["proof_len"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            # the DOMINANT KERNEL (msm_accumulate: the bucket accumulation of every MSM of a launch): algorithmic bytes of a launch over the
+            # kernel's average duration inside the timed region; the whole MSM stage (all its kernels) is in `stage`
+            "roofline": {"bound": "hbm", "achieved": acc_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": acc_gbps / HBM_PEAK_GBPS, "traffic": acc_traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "MSM stage (msm_glv_prep, msm_sort_lds, msm_seg_scan, msm_accumulate, msm_fixup, msm_window, msm_final_parts; both channels of every step of a launch)", "terms_per_launch": terms_total,
-                         "algorithmic_bytes_per_launch": 96 * terms_total,
-                         "mean_stage_ms": msm_ms, "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if isolated else "HIP events on the launch's stream, inside the timed region (other launches in flight)",
+                         "kernel": "msm_accumulate (the dominant kernel of the MSM stage: one mixed G1 addition per entry of the sorted (term, half, window) list of every MSM of a launch)",
+                         "kernel_ms": acc_timed, "kernel_ms_one_launch_in_flight": acc_ms,
+                         "timing": "the dispatch's own start / stop timestamps on the stream it is launched on (hipExtLaunchKernelGGL events), averaged over every launch of the timed region",
+                         "terms_per_launch": terms_total, "algorithmic_bytes_per_launch": 96 * terms_total,
                          "kernels": kernels,
+                         "stage": {"what": "the whole MSM stage (msm_glv_prep, msm_sort_lds, msm_seg_scan, msm_accumulate, msm_accumulate_redo, msm_fixup, msm_window, msm_final_parts; both channels of every step of a launch)",
+                                   "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "mean_stage_ms": msm_ms,
+                                   "timing": "HIP events on the launch's stream, one launch in flight (after the timed region)" if isolated else "HIP events on the launch's stream, inside the timed region (other launches in flight)"},
                          "alu": {"note": "the stage is bound by 32-bit integer multiply issue, not by HBM: achieved Fq products/s of the stage against the "
                                          "measured chip-wide peak of the Montgomery product (tools/limb29_microbench.hip)",
                                  "fq_products_per_term": 2 * 12 * 11, "fq_products_per_term_note": "2 GLV halves x 12 windows (c = 11, the 1024-proof step) x 11 per mixed addition",
