@@ -114,3 +114,26 @@ def test_strategy_mirror_with_accumulator(pool):
     whole = ctx.verify_batch(P[:10], I[:10], rand)
     assert (second.left_xy, second.right_xy) == (whole[2], whole[3])
     ctx.close()
+
+
+@pytest.mark.parametrize("mo,tr,m", [(circuits.GWC, circuits.KECCAK256, 1), (circuits.SHPLONK, circuits.BLAKE2B, 2)])
+def test_resume_with_other_instantiations(mo, tr, m):
+    """The seed is a pair of G1 accumulators: nothing in it depends on the multi-open scheme, the transcript hash or the number of
+    circuit instances per transcript — GWC / Keccak-256 and two instances per transcript resume like the headline instantiation."""
+    import halo2_verifier_amd as h2v
+    s = circuits.setup_vector_mul(8, 6).set_options(mo, tr).set_circuit_instances(m)
+    if m == 1:
+        P, I = circuits.prove_vector_mul_batch(s, 9, seed=77, threads=4)
+    else:
+        pairs = [circuits.prove_vector_mul_multi(s, m, seed=100 + i, rng_seed=7 + i) for i in range(9)]
+        P, I = [p for p, _ in pairs], [i for _, i in pairs]
+    ctx = h2v.Context(h2v.ParamsKZG(s.params, h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(s.vk, h2v.SerdeFormat.RawBytes), multiopen=mo, transcript=tr, circuit_instances=m)
+    rnd = random.Random(17)
+    rand = [rnd.randrange(1, R_MOD) for _ in P]
+    whole = ctx.verify_batch(P, I, rand)
+    assert whole[0] is True and whole == circuits.oracle_verify_batch(s, P, I, rand)
+    ok1, st1, L, R = ctx.verify_batch(P[:4], I[:4], rand[:4])
+    ok2, st2, L2, R2 = ctx.verify_batch(P[4:], I[4:], rand[4:], seed=(([1], [L]), ([1], [R])))
+    assert (ok1 and ok2, st1 + st2, L2, R2) == whole
+    ctx.close()
+    s.free()
