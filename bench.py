@@ -373,6 +373,9 @@ def rank_main(args):
 
     ctx = h2v.Context(h2v.ParamsKZG(d["params"], h2v.SerdeFormat.RawBytes), h2v.VerifyingKey(d["vk"], h2v.SerdeFormat.RawBytes), device=local_rank)
     shape = ctx.proof_shape()
+    tuning = {k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))} if args.tuning else {}
+    if tuning:   # measurement aid: forced kernel variants (h2v_ctx_set_tuning), e.g. --tuning msm_acc_waves=4; the line says so ("tuning")
+        ctx.set_tuning(**tuning)
 
     def measure(B, steps, warmup, groups, depth_arg, reupload=False, isolated_launches=0, repeats=1):
         """Time exactly `steps` steps of B proofs per GPU.  A step is one batch of B proofs per GPU with its own accumulators
@@ -577,6 +580,8 @@ def rank_main(args):
             "stages_ms_note": "HIP events between the stages, launches re-timed one at a time after the timed region (inside it only msm_accumulate is timed: an event between stages is a barrier packet, ~6 us of idle stream)",
             "stages_ms_one_launch_in_flight": isolated,
         }
+        if tuning:
+            out["tuning"] = tuning   # NOT the library's own choice of kernel variants: a measurement aid (--tuning)
         if m_re:
             out["value_reupload"] = m_re["total"] * args.steps / m_re["dt"]
             out["value_reupload_note"] = ("same K steps, host buffers (proofs, instances, draws) copied to the device again for every launch — PCIe-inclusive, SURVEY.md §8(d)'s "

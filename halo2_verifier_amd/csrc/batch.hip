@@ -154,7 +154,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     for (auto& r : runs) point_bytes += r.second;
     int mode = ctx->tuning.upload_mode;
     if (mode == 0) mode = 1;   // (one launch + finish, best of 15, tools/h2d_probe.py: resident 2.98 ms, points-first 3.29, two halves 3.33, plain 3.47;
-                               //  in the benchmark's loop the three are within its noise: tools/r03_upload_modes.sh)
+                               //  in the benchmark's loop, PCIe-inclusive over resident: 0.905 / 0.885 / 0.835, tools/r03_ab.sh)
     if (mode == 1 && (runs.size() > 4 || 2 * point_bytes > pl.proof_len)) mode = 3;   // points all over the proof, or most of it: nothing to gain
     if (n < 2048) mode = 3;                                                           // a copy of a megabyte or two is not worth two launches
     if (mode == 3) {

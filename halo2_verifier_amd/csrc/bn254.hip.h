@@ -351,6 +351,11 @@ template <class PR> struct Fp {
     // Montgomery product a*b/R mod p by product scanning: column k collects a_i*b_(k-i) and m_i*p_(k-i) in one 64-bit
     // accumulator (<= 18 terms < 2^58 each, plus a carry < 2^35), m_k is chosen to clear the column's low 29 bits.
     // Any limb-normalised inputs are safe against overflow; representatives < 2p give a result < 1.04p.
+    // (The compiler's reassociation starts every column from zero and adds the carry of the previous column last: a 64-bit add per
+    // column, 143 per mixed addition beside its 1593 multiply-adds.  Forcing the chain to start FROM the carry (an empty asm statement
+    // after each step) removes them, but every multiply-add that follows an asm statement gets an s_nop from the hazard recogniser and
+    // the products no longer interleave: 4.69 instead of 4.63 us per list entry at three waves per SIMD, 4.79 instead of 5.13 at two
+    // (tools/affine_microbench.hip, round 3).  Left to the compiler.)
     __host__ __device__ __forceinline__ static Fp mul_inl(const Fp& a, const Fp& b) {
         uint64_t acc = 0;
         uint32_t m[9];

@@ -6,7 +6,7 @@ d = sys.argv[1]; N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K " + r["Kernel_Name"].split("(")[0][-40:]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K q" + r.get("Queue_Id", "?") + " " + r["Kernel_Name"].split("(")[0][-40:]))
 for f in glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C " + r.get("Direction", "") + " " + r.get("Name", "")))
