@@ -29,5 +29,27 @@ int main() {
         (void)hipStreamSynchronize(s1); });
     rep("8 x 70 us kernels alone", [&] { for (int c = 0; c < 8; ++c) hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s1, 70 * 100ull, (int*)nullptr); (void)hipStreamSynchronize(s1); });
     rep("kernel reading 21 MB straight from pinned host memory (zero copy), 4096 x 256 lanes", [&] { (void)hipMemcpyAsync(d, pinned, 64, hipMemcpyHostToDevice, s1); (void)hipStreamSynchronize(s1); });
+    // strided (2D) copies: the point bytes of a proof are 384 of its 1024 bytes (h2v_batch_upload_launch copies them first)
+    const size_t rows = 20 * 1024, pitch = 1024, P21 = rows * pitch;
+    rep("2D copy, 384 of every 1024 B x 20480 rows (7.9 MB), pageable + sync", [&] { (void)hipMemcpy2DAsync(d, pitch, h, pitch, 384, rows, hipMemcpyHostToDevice, s1); (void)hipStreamSynchronize(s1); });
+    rep("2D copy, 640 of every 1024 B x 20480 rows (13.1 MB), pageable + sync", [&] { (void)hipMemcpy2DAsync(d + 384, pitch, h + 384, pitch, 640, rows, hipMemcpyHostToDevice, s1); (void)hipStreamSynchronize(s1); });
+    rep("2D copy, 3 runs of 128 B of every 1024 B (7.9 MB), pageable + sync", [&] { for (int r = 0; r < 3; ++r) (void)hipMemcpy2DAsync(d + 256 * r, pitch, h + 256 * r, pitch, 128, rows, hipMemcpyHostToDevice, s1); (void)hipStreamSynchronize(s1); });
+    rep("2D copy, 384 of every 1024 B from hipHostMalloc'ed memory + sync", [&] { (void)hipMemcpy2DAsync(d, pitch, pinned, pitch, 384, rows, hipMemcpyHostToDevice, s1); (void)hipStreamSynchronize(s1); });
+    rep("21 MB contiguous + 5 MB contiguous, pageable + sync", [&] { (void)hipMemcpyAsync(d, h, P21, hipMemcpyHostToDevice, s1); (void)hipMemcpyAsync(d + P21, h + P21, N - P21, hipMemcpyHostToDevice, s1); (void)hipStreamSynchronize(s1); });
+    // a stream held by hipStreamWaitValue32 on a flag the host sets (would let the later stages be enqueued before the copy they need has returned)
+    {
+        int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0);
+        printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
+        if (can) {
+            uint32_t* flag = nullptr;
+            if (hipExtMallocWithFlags((void**)&flag, 64, hipMallocSignalMemory) == hipSuccess && flag) {
+                rep("hipStreamWaitValue32 (flag already set) + 70 us kernel + sync", [&] { *flag = 1; (void)hipStreamWaitValue32(s1, flag, 1, hipStreamWaitValueEq, 0xffffffffu); hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s1, 70 * 100ull, (int*)nullptr); (void)hipStreamSynchronize(s1); });
+                rep("hipStreamWaitValue32, flag set by the host after a 21 MB blocking copy on another stream, + 70 us kernel", [&] {
+                    *flag = 0; (void)hipStreamWaitValue32(s1, flag, 1, hipStreamWaitValueEq, 0xffffffffu); hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s1, 70 * 100ull, (int*)nullptr);
+                    (void)hipMemcpyAsync(d, h, P21, hipMemcpyHostToDevice, s2); (void)hipStreamSynchronize(s2); *flag = 1; (void)hipStreamSynchronize(s1); });
+                (void)hipFree(flag);
+            } else printf("hipExtMallocWithFlags(hipMallocSignalMemory) failed\n");
+        }
+    }
     return 0;
 }
