@@ -138,8 +138,9 @@ std::vector<uint32_t> pairing_program(bool merged) {
 //   the tail of the hard part pairs what is independent (y9 | y10, y12 | y11, ...).
 // Both groups step together (two barriers per step); a step's two operations never write, or write and read, the same register.
 // One step = uint2 (operation of A, operation of B), 0 = nothing to do.
-#define PAIR2_REGS 20
-#define PAIR2_MAX_STEPS 448
+#define PAIR2_LOGICAL_REGS 19   // the table below names registers 0 .. 18
+#define PAIR2_REGS 22           // physical registers: a product never writes a register that any operation of its step reads (below)
+#define PAIR2_MAX_STEPS H2V_PAIR2_MAX_STEPS
 std::vector<uint32_t> pairing_program2() {
     std::vector<uint32_t> A, B;
     enum { FA = 0, FB = 1, R = 2, T0 = 3, T1 = 4, T2 = 5, T3 = 6, T4 = 7, T5 = 8, T6 = 9, TAB = 10, D2 = 18 };
@@ -232,6 +233,32 @@ std::vector<uint32_t> pairing_program2() {
     a1(MUL(y0, y1, y0));                   // y16
     a1(pair_op(P_CHECK, 0, y0, 0));
     sync();
+    // Physical registers.  k_pairing2 runs a product in ONE phase — operands read at its start, result written at its end, one barrier
+    // per step — so a product's destination must not be a register that anything in the same step still reads (f <- f^2 in place
+    // would race).  Every product therefore writes a fresh physical register; the one its logical register held before is free
+    // again from the next step on.  Two products per step at most: two spare registers are enough, PAIR2_REGS has three.
+    // (Coefficient-wise operations stay in place: each lane reads its coefficient before it writes it, all within one wave.)
+    {
+        std::vector<uint32_t> map(PAIR2_LOGICAL_REGS), spare;
+        for (uint32_t r = 0; r < PAIR2_LOGICAL_REGS; ++r) map[r] = r;
+        for (uint32_t r = PAIR2_REGS; r-- > PAIR2_LOGICAL_REGS;) spare.push_back(r);
+        for (size_t i = 0; i < A.size(); ++i) {
+            uint32_t* w[2] = {&A[i], &B[i]};
+            uint32_t newd[2] = {0, 0}, logd[2] = {0, 0}; bool renamed[2] = {false, false};
+            std::vector<uint32_t> release;
+            for (int c = 0; c < 2; ++c) {   // sources through the map as it stands BEFORE this step, for both columns
+                const uint32_t x = *w[c], op = x & 255u, d = (x >> 8) & 255u, a = (x >> 16) & 255u, b = x >> 24;
+                if (!op) continue;
+                const bool product = op >= P_SQR && op <= P_MULL;
+                const uint32_t pa = map[a], pb = op == P_MUL ? map[b] : b;   // P_MULL: b is a line index
+                uint32_t pd2 = op == P_CHECK ? 0u : map[d];
+                if (product) { pd2 = spare.back(); spare.pop_back(); release.push_back(map[d]); renamed[c] = true; newd[c] = pd2; logd[c] = d; }
+                *w[c] = pair_op(op, pd2, pa, pb);
+            }
+            for (int c = 0; c < 2; ++c) if (renamed[c]) map[logd[c]] = newd[c];
+            for (uint32_t r : release) spare.push_back(r);
+        }
+    }
     std::vector<uint32_t> steps;
     for (size_t i = 0; i < A.size(); ++i) { steps.push_back(A[i]); steps.push_back(B[i]); }
     return steps;
@@ -419,14 +446,131 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
     }
 }
 
-// Two operation streams per check (pairing_program2): 256 threads, group g = t / 128 executes column g of every step.  The line
-// products always come from k_pair_lines.
+// ---- k_pairing2: two operation streams per check (pairing_program2), 256 threads, group g = t / 128 executes column g of every step;
+// the line products always come from k_pair_lines.
+//
+// A product is ONE phase here (round 3; k_pairing above keeps the two-phase form: 72 dot2 lanes, LDS, barrier, fold lanes, barrier —
+// measured inside this kernel at 2390 + 80 + 2650 + 70 cycles per step, the fold the larger half).  The result's coordinate
+// (k, re / im) is a sum of six Fq2-product coordinates, a_i * b_j over i + j = k and xi a_i * b_j over i + j = k + 6, i.e. of twelve Fq
+// products.  EIGHT LANES own one output: lane i of the group computes term i as the 18-limb integer a_i0 B0 + a_i1 B1 WITHOUT a
+// reduction (162 multiply-adds, one carry sweep), the eight lanes add their limbs with three DPP steps (quad_perm, quad_perm,
+// row_half_mirror: 32-bit adds, six terms of 29-bit limbs fit), and ONE Montgomery reduction per output follows — 12 instead of 72,
+// no partial products through LDS, no barrier between "products" and "fold".  No subtraction anywhere: a register keeps SIX forms of
+// every coefficient c = c0 + c1 u — c0, c1, -c1, and xi c = (9 c0 - c1) + (9 c1 + c0) u with its negated imaginary part — so B0, B1
+// are always stored values: re: (c0, -c1) or (xi c)_0, -(xi c)_1; im: (c1, c0) or (xi c)_1, (xi c)_0.  The groups of (k, re) and
+// (k, im) share a 16-lane row: they swap their reduced values with one row rotation and lanes 0 .. 5 of the re group each derive and
+// store one of the six forms (integer weights on the limbs, one from_wide: every stored form is below 2p, so the twelve products of
+// an output sum to less than 48 p^2 and its reduction to less than 1.3 p).
+struct Coef6 { Fq f[6]; };   // c0, c1, -c1, 9 c0 - c1, 9 c1 + c0, -(9 c1 + c0): non-negative representatives below 2p
+// form `which` of the coefficient re + im u, both limb-normalised and below 4p
+__device__ __forceinline__ Fq coef_form(const Fq& re, const Fq& im, uint32_t which) {
+    const int32_t alpha = which == 0 ? 1 : (which == 3 ? 9 : (which == 4 ? 1 : (which == 5 ? -1 : 0)));
+    const int32_t beta = which == 1 ? 1 : (which == 2 ? -1 : (which == 3 ? -1 : (which == 4 ? 9 : (which == 5 ? -9 : 0))));
+    const int32_t kappa = which == 2 ? 4 : (which == 3 ? 4 : (which == 5 ? 40 : 0));   // keeps alpha re + beta im + kappa p >= 0 (and below 80p < 2^261)
+    int64_t acc[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) acc[l] = (int64_t)alpha * (int64_t)re.v[l] + (int64_t)beta * (int64_t)im.v[l] + (int64_t)kappa * (int64_t)FqParams::P29(l);
+    return Fq::from_wide(acc);
+}
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xf, 0xf, true); }
+// one product step of a group: lane tl = 8 * (2 k + coordinate) + term
+__device__ __forceinline__ void pair_step6(uint32_t op, uint32_t rd, uint32_t ra, uint32_t rb, const Fq2 (*line)[6], Coef6 (*reg)[6], uint32_t tl) {
+    const uint32_t out = tl >> 3, term = tl & 7u;
+    const bool active = out < 12 && term < 6;
+    const uint32_t k = active ? out >> 1 : 0, i = active ? term : 0, coord = out & 1u;
+    const bool high = i > k;                          // i + j = k + 6: the term carries xi
+    const uint32_t j = high ? k + 6 - i : k - i;
+    // A: the factor taken as it is (a line, or coefficient i of register ra); B: coefficient j of the other factor, in the stored form the term needs
+    const Fq* pa = op == P_MULL ? &line[rb][i].c0 : &reg[ra][i].f[0];   // (c0, c1) are adjacent in both
+    const Coef6* pb = &reg[op == P_MULL ? ra : (op == P_SQR ? ra : rb)][j];
+    const uint32_t s0 = coord ? (high ? 4u : 1u) : (high ? 3u : 0u), s1 = coord ? (high ? 3u : 0u) : (high ? 5u : 2u);
+    Fq A0 = pa[0], A1 = pa[1];
+    const Fq B0 = pb->f[s0], B1 = pb->f[s1];
+    if (!active) { A0 = Fq::zero(); A1 = Fq::zero(); }
+    // the term as an 18-limb integer (below 2 * 2p * 2p)
+    uint32_t T[18];
+    {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int c = 0; c < 17; ++c) {
+#pragma unroll
+            for (int x = (c > 8 ? c - 8 : 0); x <= (c < 8 ? c : 8); ++x) { acc += (uint64_t)A0.v[x] * B0.v[c - x]; acc += (uint64_t)A1.v[x] * B1.v[c - x]; }
+            T[c] = (uint32_t)acc & H2V_LIMB_MASK;
+            acc >>= 29;
+        }
+        T[17] = (uint32_t)acc;
+    }
+    // the six terms of the output, limb by limb (every lane of the eight ends with the sum)
+#pragma unroll
+    for (int c = 0; c < 18; ++c) {
+        uint32_t x = T[c];
+        x += dpp_u32<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+        x += dpp_u32<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+        x += dpp_u32<0x141>(x);   // row_half_mirror: the other quad of the eight
+        T[c] = x;
+    }
+    // one Montgomery reduction (R = 2^261) of the 18 limbs (each below 6 * 2^29)
+    Fq r;
+    {
+        uint64_t acc = 0;
+        uint32_t m[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            acc += T[c];
+#pragma unroll
+            for (int x = 0; x < c; ++x) acc += (uint64_t)m[x] * FqParams::P29(c - x);
+            m[c] = ((uint32_t)acc * FqParams::INV29) & H2V_LIMB_MASK;
+            acc += (uint64_t)m[c] * FqParams::P29(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int c = 9; c < 17; ++c) {
+            acc += T[c];
+#pragma unroll
+            for (int x = c - 8; x <= 8; ++x) acc += (uint64_t)m[x] * FqParams::P29(c - x);
+            r.v[c - 9] = (uint32_t)acc & H2V_LIMB_MASK;
+            acc >>= 29;
+        }
+        r.v[8] = (uint32_t)acc + T[17];
+    }
+    // the other coordinate of the coefficient sits eight lanes away in the same row
+    Fq o;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) o.v[l] = dpp_u32<0x128>(r.v[l]);   // row_ror:8
+    const Fq f = coef_form(coord ? o : r, coord ? r : o, i);
+    if (active && coord == 0) reg[rd][k].f[i] = f;
+}
+// coefficient-wise operations on the six-form registers: lane (coefficient k, form) for t < 36, all in the group's first wave
+__device__ __forceinline__ void pair_coefficients6(uint32_t op, uint32_t rd, uint32_t ra, Coef6 (*reg)[6], const PairingConsts* __restrict__ consts, uint32_t t) {
+    if (t >= 36) return;
+    const uint32_t k = t / 6, which = t % 6;
+    const Coef6& x = reg[ra][k];
+    Fq re = x.f[0], im = x.f[1];
+    if (op == P_CONJ) {            // x^(p^6): w -> -w
+        if (k & 1u) { re = Fq::lazy_neg(re); im = x.f[2]; }
+    } else if (op == P_FROB) {     // x^p: conjugate every coefficient, times gamma^k
+        if (k == 0) im = x.f[2];
+        else { const Fq2 m = Fq2::mul(Fq2{x.f[0], x.f[2]}, consts->gamma1[k]); re = m.c0; im = m.c1; }
+    } else if (op == P_INV2) {     // coefficient 0 <- its inverse in Fq2, the others <- 0
+        if (k == 0) {
+            const Fq nrm = x.f[0].sqr() + x.f[1].sqr();
+            const Fq ni = nrm.inv();
+            re = x.f[0] * ni; im = x.f[2] * ni;
+        } else { re = Fq::zero(); im = Fq::zero(); }
+    }
+    reg[rd][k].f[which] = coef_form(re, im, which);   // P_COPY: as it was
+}
+__device__ __forceinline__ bool pair_is_one6(const Coef6* x) {
+    bool one = x[0].f[0] == Fq::one() && x[0].f[1].is_zero();
+    for (int k2 = 1; k2 < 6; ++k2) one = one && x[k2].f[0].is_zero() && x[k2].f[1].is_zero();
+    return one;
+}
 struct alignas(16) PairShared2 {
     Fq2 line[PAIR_ITERS][6];
-    Fq2 prod[2][37];              // [36] stays zero (fq12_fold)
-    Coef reg[PAIR2_REGS][6];
+    Coef6 reg[PAIR2_REGS][6];
     uint2 prog[PAIR2_MAX_STEPS];
 };
+static_assert(sizeof(PairShared2) <= 64 * 1024, "k_pairing2's static LDS");
 __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, const PairingConsts* __restrict__ consts, const uint2* __restrict__ prog, uint32_t n_steps,
                                                                const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
     __builtin_amdgcn_s_setprio(3);
@@ -438,12 +582,11 @@ __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, co
         uint4* dst = reinterpret_cast<uint4*>(&s.line[0][0]);
         for (uint32_t k = t; k < PAIR_ITERS * 6 * sizeof(Fq2) / 16; k += 2 * PAIR_THREADS) dst[k] = src[k];
     }
-    if (t < 12) {   // registers 0 and 1 (the two halves of the Miller value) start at one
-        Coef c; c.c0 = (t % 6) == 0 ? Fq::one() : Fq::zero(); c.c1 = Fq::zero(); c.n1 = Fq::zero();
-        s.reg[t / 6][t % 6] = c;
+    if (t < 72) {   // registers 0 and 1 (the two halves of the Miller value) start at one: lane (register, coefficient, form)
+        const uint32_t k = (t % 36) / 6;
+        s.reg[t / 36][k].f[t % 6] = coef_form(k == 0 ? Fq::one() : Fq::zero(), Fq::zero(), t % 6);
     }
     for (uint32_t k = t; k < n_steps; k += 2 * PAIR_THREADS) s.prog[k] = prog[k];
-    if (tl == 0) s.prod[g][36] = Fq2::zero();
     __syncthreads();
     uint2 w2_next = s.prog[0];
     for (uint32_t pc = 0; pc < n_steps; ++pc) {
@@ -451,13 +594,10 @@ __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, co
         w2_next = s.prog[pc + 1 < n_steps ? pc + 1 : pc];   // the next step's words are read while this one runs: no LDS round trip between a barrier and the decode
         const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g ? w2.y : w2.x));   // uniform per wave: decoded on the scalar unit
         const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
-        const bool product = op >= P_SQR && op <= P_MULL;
-        if (product) pair_products(op, ra, rb, s.line, s.reg, s.prod[g], tl);
-        else if (op == P_CHECK) { if (tl == 0) ok[chk] = pair_is_one(s.reg[ra]) ? 1u : 0u; }
-        else if (op) pair_coefficients(op, rd, ra, s.reg, consts, tl);
-        __syncthreads();
-        if (product && tl < 72) fq12_fold(s.prod[g], s.reg[rd], tl);
-        __syncthreads();
+        if (op >= P_SQR && op <= P_MULL) pair_step6(op, rd, ra, rb, s.line, s.reg, tl);
+        else if (op == P_CHECK) { if (tl == 0) ok[chk] = pair_is_one6(s.reg[ra]) ? 1u : 0u; }
+        else if (op) pair_coefficients6(op, rd, ra, s.reg, consts, tl);
+        __syncthreads();   // the one barrier of a step: a product's destination is a register nothing in its step reads (pairing_program2)
     }
 }
 

@@ -17,6 +17,7 @@ bool params_from_bytes(const uint8_t* data, size_t len, int format, ParamsHost& 
 PairingConsts pairing_consts_host();
 std::vector<uint32_t> pairing_program(bool merged_lines);
 std::vector<uint32_t> pairing_program2();   // two operation streams per check: [step][2]
+#define H2V_PAIR2_MAX_STEPS 352             // steps k_pairing2 holds in LDS (the table has 330)
 
 #define H2V_PAIRING_LINES 102   // 64 doublings + popcount(ATE_LOW) = 36 additions + 2 Frobenius corrections
 #define H2V_PAIRING_LINE_WS_BYTES ((size_t)66 * 6 * sizeof(Fq2))   // per check: k_pair_lines' output, one Fq12 per Miller iteration (+ 2 corrections)

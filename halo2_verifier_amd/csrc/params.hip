@@ -136,7 +136,7 @@ int PairingDevice::upload(const ParamsHost& p) {
     H2V_HIP_CHECK(hipMemcpy(prog_merged, opsm.data(), 4 * opsm.size(), hipMemcpyHostToDevice));
     const std::vector<uint32_t> ops2 = pairing_program2();
     n_steps2 = (uint32_t)(ops2.size() / 2);
-    if (n_steps2 > 448) { set_last_error("pairing: two-stream table too long"); return H2V_ERR_DEVICE; }
+    if (n_steps2 > H2V_PAIR2_MAX_STEPS) { set_last_error("pairing: two-stream table too long"); return H2V_ERR_DEVICE; }
     H2V_HIP_CHECK(hipMalloc(&prog2, 4 * ops2.size()));
     H2V_HIP_CHECK(hipMemcpy(prog2, ops2.data(), 4 * ops2.size(), hipMemcpyHostToDevice));
     return 0;
