@@ -237,7 +237,8 @@ std::vector<uint32_t> pairing_program2() {
     // per step — so a product's destination must not be a register that anything in the same step still reads (f <- f^2 in place
     // would race).  Every product therefore writes a fresh physical register; the one its logical register held before is free
     // again from the next step on.  Two products per step at most: two spare registers are enough, PAIR2_REGS has three.
-    // (Coefficient-wise operations stay in place: each lane reads its coefficient before it writes it, all within one wave.)
+    // (The Frobenius is treated like a product.  Conjugation, copy and the inversion stay in place: each lane reads its coefficient
+    // before it writes it, all within one wave.)
     {
         std::vector<uint32_t> map(PAIR2_LOGICAL_REGS), spare;
         for (uint32_t r = 0; r < PAIR2_LOGICAL_REGS; ++r) map[r] = r;
@@ -249,7 +250,7 @@ std::vector<uint32_t> pairing_program2() {
             for (int c = 0; c < 2; ++c) {   // sources through the map as it stands BEFORE this step, for both columns
                 const uint32_t x = *w[c], op = x & 255u, d = (x >> 8) & 255u, a = (x >> 16) & 255u, b = x >> 24;
                 if (!op) continue;
-                const bool product = op >= P_SQR && op <= P_MULL;
+                const bool product = (op >= P_SQR && op <= P_MULL) || op == P_FROB;   // (the Frobenius runs on lanes of two waves: not in place either)
                 const uint32_t pa = map[a], pb = op == P_MUL ? map[b] : b;   // P_MULL: b is a line index
                 uint32_t pd2 = op == P_CHECK ? 0u : map[d];
                 if (product) { pd2 = spare.back(); spare.pop_back(); release.push_back(map[d]); renamed[c] = true; newd[c] = pd2; logd[c] = d; }
@@ -540,17 +541,30 @@ __device__ __forceinline__ void pair_step6(uint32_t op, uint32_t rd, uint32_t ra
     const Fq f = coef_form(coord ? o : r, coord ? r : o, i);
     if (active && coord == 0) reg[rd][k].f[i] = f;
 }
-// coefficient-wise operations on the six-form registers: lane (coefficient k, form) for t < 36, all in the group's first wave
+// coefficient-wise operations on the six-form registers.  Conjugation / copy / the inversion: lane (coefficient k, form) for t < 36, all
+// in the group's first wave (a lane reads its coefficient before any lane writes it: these may run in place).  Frobenius (never in
+// place: pairing_program2 gives it a fresh destination): lane (k, form, coordinate) for t < 72 — conj(c) gamma^k as two dot2 over stored forms, re = c0 g0 + c1 g1, im = c0 g1 +
+// (-c1) g0, one per lane of a pair; the pair swaps them (as a call to Fq2::mul on every lane this step cost 8700 cycles, a product step 3700).
 __device__ __forceinline__ void pair_coefficients6(uint32_t op, uint32_t rd, uint32_t ra, Coef6 (*reg)[6], const PairingConsts* __restrict__ consts, uint32_t t) {
+    if (op == P_FROB) {
+        if (t >= 72) return;
+        const uint32_t k = t / 12, which = (t % 12) >> 1, coord = t & 1u;
+        const Coef6& x = reg[ra][k];
+        const Fq2 gm = consts->gamma1[k];                        // gamma^0 = 1: (c0, -c1) comes out of the same two dot2
+        const Fq mine = Fq::dot2_inl(x.f[0], coord ? gm.c1 : gm.c0, coord ? x.f[2] : x.f[1], coord ? gm.c0 : gm.c1);
+        Fq other;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) other.v[l] = dpp_u32<0xB1>(mine.v[l]);   // quad_perm [1, 0, 3, 2]: the pair's other coordinate
+        const Fq f = coef_form(coord ? other : mine, coord ? mine : other, which);
+        if (coord == 0) reg[rd][k].f[which] = f;
+        return;
+    }
     if (t >= 36) return;
     const uint32_t k = t / 6, which = t % 6;
     const Coef6& x = reg[ra][k];
     Fq re = x.f[0], im = x.f[1];
     if (op == P_CONJ) {            // x^(p^6): w -> -w
         if (k & 1u) { re = Fq::lazy_neg(re); im = x.f[2]; }
-    } else if (op == P_FROB) {     // x^p: conjugate every coefficient, times gamma^k
-        if (k == 0) im = x.f[2];
-        else { const Fq2 m = Fq2::mul(Fq2{x.f[0], x.f[2]}, consts->gamma1[k]); re = m.c0; im = m.c1; }
     } else if (op == P_INV2) {     // coefficient 0 <- its inverse in Fq2, the others <- 0
         if (k == 0) {
             const Fq nrm = x.f[0].sqr() + x.f[1].sqr();
