@@ -122,3 +122,34 @@ def test_pairing_relations(ctx, srs):
     assert ctx.pairing_check(g1_xy(srs.g[3]), g1_xy(srs.g[5])) is False
     assert ctx.pairing_check(bytes(64), bytes(64)) is True     # empty accumulator
     assert ctx.pairing_check(g1_xy(srs.g[3]), bytes(64)) is False
+
+
+def test_pairing_verdicts_random_against_oracle(ctx, srs, oracle):
+    """DualMSM::check verdicts on seeded pairs, GPU against the oracle's textbook final exponentiation.  The GPU kernels carry the
+    scalar nu = |Norm(f conj f)|^2 through the final exponentiation instead of inverting it and test membership in Fq* at the end
+    (csrc/pairing.hip: pairing_program): the same verdict for every input, checked here on relations that hold (left = sum a_i [s^i],
+    right = sum a_i [s^(i+1)]) and on near misses (one coefficient off by one, sides swapped, one side the identity)."""
+    rnd = random.Random(99)
+    L = oracle
+    cases = []
+    for t in range(12):
+        m = rnd.randrange(1, 6)
+        idx = [rnd.randrange(0, 250) for _ in range(m)]
+        a = [rnd.randrange(1, R_MOD) for _ in range(m)]
+        left = oracle_lib.g1_msm(L, a, [g1_xy(srs.g[i]) for i in idx])
+        right = oracle_lib.g1_msm(L, a, [g1_xy(srs.g[i + 1]) for i in idx])
+        cases.append((left, right))                                   # holds
+        b = list(a); b[0] = (b[0] + 1) % R_MOD or 1
+        cases.append((left, oracle_lib.g1_msm(L, b, [g1_xy(srs.g[i + 1]) for i in idx])))   # one coefficient off
+        cases.append((right, left))                                   # swapped
+        if t % 4 == 0:
+            cases.append((left, bytes(64)))
+            cases.append((bytes(64), right))
+    want = []
+    for left, right in cases:
+        ok = ctypes.c_int(-1)
+        assert L.h2o_pairing_check(srs.params_raw, len(srs.params_raw), 1, left, right, ctypes.byref(ok)) == 0
+        want.append(bool(ok.value))
+    got = [ctx.pairing_check(left, right) for left, right in cases]
+    assert got == want
+    assert want.count(True) == 12 and want.count(False) == len(cases) - 12

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r03_ab3
-for t in "none" "msm_window_threads=128" "msm_window_threads=128,msm_window_slots=3" "msm_window_slots=3" "none2"; do
+for t in "none" "msm_window_threads=64,msm_window_wpw=4" "msm_window_threads=64,msm_window_wpw=2" "msm_window_threads=64,msm_window_wpw=4,msm_window_slots=3" "none2"; do
   f=gpurun_out/r03_ab3/$(echo $t | tr '=,' '__').json
   case $t in none*) T="";; *) T="--tuning $t";; esac
   timeout -k 10 120 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-reupload-leg --no-extra-legs $T > $f 2> ${f%.json}.err || exit 1
