@@ -37,11 +37,41 @@ namespace h2v {
 #define N_LINES H2V_PAIRING_LINES
 #define PAIR_ITERS 66        // line products of the merged program: 64 Miller iterations + the two Frobenius corrections
 #define PAIR_THREADS 128
-#define PAIR_REGS 17
+#define PAIR_REGS 17         // logical registers of the single-stream table
+#define PAIR1_REGS 19        // physical registers of k_pairing (a product writes a fresh one: pair_rename_registers)
 #define PAIR_MAX_OPS 512
 
 enum PairOpCode : uint32_t { P_SQR = 1, P_MUL = 2, P_MULL = 3, P_CONJ = 4, P_FROB = 5, P_CONJ0 = 6, P_COPY = 7, P_CHECK = 8 };
 static inline uint32_t pair_op(uint32_t op, uint32_t d, uint32_t a, uint32_t b) { return op | (d << 8) | (a << 16) | (b << 24); }
+
+// Physical registers.  The kernels run a product in ONE phase — operands read at its start, result written at its end, one barrier per
+// step — so a product's destination must not be a register that anything in the same step still reads (f <- f^2 in place would race).
+// Every product (and every Frobenius: its lanes span two waves) therefore writes a fresh physical register; the one its logical
+// register held before is free again from the next step on.  `cols`: the operation columns of a step (one, or two for k_pairing2);
+// at most one renamed operation per column and step, so n_phys - n_logical >= the number of columns.  Conjugations and copies stay
+// in place: each lane reads its coefficient before it writes it, all within one wave.
+static void pair_rename_registers(std::vector<std::vector<uint32_t>*> cols, uint32_t n_logical, uint32_t n_phys) {
+    std::vector<uint32_t> map(n_logical), spare;
+    for (uint32_t r = 0; r < n_logical; ++r) map[r] = r;
+    for (uint32_t r = n_phys; r-- > n_logical;) spare.push_back(r);
+    const size_t steps = cols[0]->size();
+    for (size_t i = 0; i < steps; ++i) {
+        std::vector<std::pair<uint32_t, uint32_t>> renamed;   // (logical, new physical)
+        std::vector<uint32_t> release;
+        for (auto* col : cols) {   // sources through the map as it stands BEFORE this step, for every column
+            uint32_t& x = (*col)[i];
+            const uint32_t op = x & 255u, d = (x >> 8) & 255u, a = (x >> 16) & 255u, b = x >> 24;
+            if (!op) continue;
+            const bool fresh = (op >= P_SQR && op <= P_MULL) || op == P_FROB;
+            const uint32_t pa = map[a], pb = op == P_MUL ? map[b] : b;   // P_MULL: b is a line index
+            uint32_t pd2 = op == P_CHECK ? 0u : map[d];
+            if (fresh) { pd2 = spare.back(); spare.pop_back(); release.push_back(map[d]); renamed.push_back({d, pd2}); }
+            x = pair_op(op, pd2, pa, pb);
+        }
+        for (auto& r : renamed) map[r.first] = r.second;
+        for (uint32_t r : release) spare.push_back(r);
+    }
+}
 
 // The operation table of one pairing check (host, once per context).  Registers: 0 = f, 1 = r, 2.. = temporaries.
 std::vector<uint32_t> pairing_program(bool merged) {
@@ -131,6 +161,7 @@ std::vector<uint32_t> pairing_program(bool merged) {
     frob(y1, y1); frob(y1, y1); frob(y1, y1);   // y15
     mul(y0, y1, y0);                   // y16
     p.push_back(pair_op(P_CHECK, 0, y0, 0));
+    pair_rename_registers({&p}, PAIR_REGS, PAIR1_REGS);
     return p;
 }
 
@@ -145,7 +176,7 @@ std::vector<uint32_t> pairing_program(bool merged) {
 // Both groups step together (two barriers per step); a step's two operations never write, or write and read, the same register.
 // One step = uint2 (operation of A, operation of B), 0 = nothing to do.
 #define PAIR2_LOGICAL_REGS 19   // the table below names registers 0 .. 18
-#define PAIR2_REGS 22           // physical registers: a product never writes a register that any operation of its step reads (below)
+#define PAIR2_REGS 22           // physical registers (pair_rename_registers)
 #define PAIR2_MAX_STEPS H2V_PAIR2_MAX_STEPS
 std::vector<uint32_t> pairing_program2() {
     std::vector<uint32_t> A, B;
@@ -239,45 +270,13 @@ std::vector<uint32_t> pairing_program2() {
     a1(MUL(y0, y1, y0));                   // y16
     a1(pair_op(P_CHECK, 0, y0, 0));
     sync();
-    // Physical registers.  k_pairing2 runs a product in ONE phase — operands read at its start, result written at its end, one barrier
-    // per step — so a product's destination must not be a register that anything in the same step still reads (f <- f^2 in place
-    // would race).  Every product therefore writes a fresh physical register; the one its logical register held before is free
-    // again from the next step on.  Two products per step at most: two spare registers are enough, PAIR2_REGS has three.
-    // (The Frobenius is treated like a product.  Conjugations and copies stay in place: each lane reads its coefficient
-    // before it writes it, all within one wave.)
-    {
-        std::vector<uint32_t> map(PAIR2_LOGICAL_REGS), spare;
-        for (uint32_t r = 0; r < PAIR2_LOGICAL_REGS; ++r) map[r] = r;
-        for (uint32_t r = PAIR2_REGS; r-- > PAIR2_LOGICAL_REGS;) spare.push_back(r);
-        for (size_t i = 0; i < A.size(); ++i) {
-            uint32_t* w[2] = {&A[i], &B[i]};
-            uint32_t newd[2] = {0, 0}, logd[2] = {0, 0}; bool renamed[2] = {false, false};
-            std::vector<uint32_t> release;
-            for (int c = 0; c < 2; ++c) {   // sources through the map as it stands BEFORE this step, for both columns
-                const uint32_t x = *w[c], op = x & 255u, d = (x >> 8) & 255u, a = (x >> 16) & 255u, b = x >> 24;
-                if (!op) continue;
-                const bool product = (op >= P_SQR && op <= P_MULL) || op == P_FROB;   // (the Frobenius runs on lanes of two waves: not in place either)
-                const uint32_t pa = map[a], pb = op == P_MUL ? map[b] : b;   // P_MULL: b is a line index
-                uint32_t pd2 = op == P_CHECK ? 0u : map[d];
-                if (product) { pd2 = spare.back(); spare.pop_back(); release.push_back(map[d]); renamed[c] = true; newd[c] = pd2; logd[c] = d; }
-                *w[c] = pair_op(op, pd2, pa, pb);
-            }
-            for (int c = 0; c < 2; ++c) if (renamed[c]) map[logd[c]] = newd[c];
-            for (uint32_t r : release) spare.push_back(r);
-        }
-    }
+    pair_rename_registers({&A, &B}, PAIR2_LOGICAL_REGS, PAIR2_REGS);
     std::vector<uint32_t> steps;
     for (size_t i = 0; i < A.size(); ++i) { steps.push_back(A[i]); steps.push_back(B[i]); }
     return steps;
 }
 
 struct Coef { Fq c0, c1, n1; };   // an Fq2 coefficient and the negated imaginary part: n1 = -c1
-struct alignas(16) PairShared {
-    Fq2 line[N_LINES][6];         // per Miller step: the product of the step's line values, coefficients of w^0 .. w^5 (two lines: w^5 is zero)
-    Fq2 prod[37];                 // partial products a_i * b_j at [6 i + j]; [36] stays zero (fq12_fold)
-    Coef reg[PAIR_REGS][6];
-    uint32_t prog[PAIR_MAX_OPS];  // the operation table, copied once: one LDS broadcast read per operation instead of a memory load
-};
 
 // k-fold multiples of p on the limbs (offsets that keep the fold's integer combinations non-negative)
 __device__ __forceinline__ int64_t p_times(int l, int64_t k) { return k * (int64_t)FqParams::P29(l); }
@@ -327,135 +326,11 @@ __device__ __forceinline__ void fq12_fold(const Fq2* prod, Coef* dst, uint32_t t
     }
 }
 
-// ---- the two kinds of steps of the operation table, shared by k_pairing (one operation per step) and k_pairing2 (two)
-// products: one dot2 per lane t of the 128 that execute the operation; line = the Miller-line table, reg = the register file
-__device__ __forceinline__ void pair_products(uint32_t op, uint32_t ra, uint32_t rb, const Fq2 (*line)[6], const Coef (*reg)[6], Fq2* prod, uint32_t t) {
-    const uint32_t pr = t >> 1, coord = t & 1u;
-    uint32_t i = 0, j = 0;
-    bool active;
-    const Fq *a0, *a1;        // the factor that needs no negation
-    const Coef* bb;           // the factor whose -c1 is stored
-    if (op == P_SQR) {
-        active = t < 42;
-        // pair number -> (i, j), i <= j, rows of lengths 6, 5, 4, 3, 2, 1
-        uint32_t base = 0;
-        i = pr >= 6 ? 1 : 0; base = pr >= 6 ? 6 : 0;
-        if (pr >= 11) { i = 2; base = 11; }
-        if (pr >= 15) { i = 3; base = 15; }
-        if (pr >= 18) { i = 4; base = 18; }
-        if (pr >= 20) { i = 5; base = 20; }
-        j = i + (pr - base);
-        if (!active) { i = 0; j = 0; }
-        a0 = &reg[ra][i].c0; a1 = &reg[ra][i].c1; bb = &reg[ra][j];
-    } else if (op == P_MUL) {
-        active = t < 72;
-        i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;
-        a0 = &reg[ra][i].c0; a1 = &reg[ra][i].c1; bb = &reg[rb][j];
-    } else {
-        active = t < 72;
-        i = active ? pr / 6 : 0; j = active ? pr % 6 : 0;     // x_i * l_j
-        a0 = &line[rb][j].c0; a1 = &line[rb][j].c1; bb = &reg[ra][i];
-    }
-    if (active) {
-        const Fq A0 = *a0, A1 = *a1;
-        const Fq B0 = coord ? bb->c1 : bb->c0, B1 = coord ? bb->c0 : bb->n1;
-        const Fq r = Fq::dot2_inl(A0, B0, A1, B1);
-        Fq* dst = coord ? &prod[i * 6 + j].c1 : &prod[i * 6 + j].c0;
-        *dst = r;
-        if (op == P_SQR && i != j) { Fq* d2 = coord ? &prod[j * 6 + i].c1 : &prod[j * 6 + i].c0; *d2 = r; }
-    }
-}
-// coefficient-wise operations, one lane per coefficient (t < 6)
-__device__ __forceinline__ void pair_coefficients(uint32_t op, uint32_t rd, uint32_t ra, Coef (*reg)[6], const PairingConsts* __restrict__ consts, uint32_t t) {
-    if (t >= 6) return;
-    const Coef x = reg[ra][t];
-    Coef r = x;
-    if (op == P_CONJ) {            // x^(p^6): w -> -w
-        if (t & 1u) { r.c0 = x.c0.neg(); r.c1 = x.n1; r.n1 = x.c1; }
-    } else if (op == P_FROB) {     // x^p: conjugate every coefficient, times gamma^k
-        if (t == 0) { r.c1 = x.n1; r.n1 = x.c1; }
-        else {
-            const Fq2 m = Fq2::mul(Fq2{x.c0, x.n1}, consts->gamma1[t]);
-            r.c0 = m.c0; r.c1 = m.c1; r.n1 = m.c1.neg();
-        }
-    } else if (op == P_CONJ0) {    // an element of Fq2 (coefficient 0): its conjugate; the other coefficients <- 0
-        if (t == 0) { r.c1 = x.n1; r.n1 = x.c1; }
-        else { r.c0 = Fq::zero(); r.c1 = Fq::zero(); r.n1 = Fq::zero(); }
-    }
-    reg[rd][t] = r;                // P_COPY: r = x
-}
-// the end of the table: the value is lambda^E y (pairing_program): the check passes iff it lies in Fq*
-__device__ __forceinline__ bool pair_in_fq_star(const Coef* x) {
-    bool in = !x[0].c0.is_zero() && x[0].c1.is_zero();
-    for (int k2 = 1; k2 < 6; ++k2) in = in && x[k2].c0.is_zero() && x[k2].c1.is_zero();
-    return in;
-}
-
-__global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
-                                                          const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
-                                                          const uint32_t* __restrict__ prog, uint32_t n_ops, const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
-    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
-    __shared__ PairShared s;
-    const uint32_t chk = blockIdx.x, t = threadIdx.x;
-    if (chk >= n) return;
-    if (pre) {
-        // the steps' line products come ready from k_pair_lines (a check over split accumulators: 2 * parts lines per step)
-        const uint4* src = reinterpret_cast<const uint4*>(pre + (size_t)chk * PAIR_ITERS * 6);
-        uint4* dst = reinterpret_cast<uint4*>(&s.line[0][0]);
-        for (uint32_t k = t; k < PAIR_ITERS * 6 * sizeof(Fq2) / 16; k += PAIR_THREADS) dst[k] = src[k];
-    } else {
-        const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
-        const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
-        // line l(P) = a*y + b*x*w + c*w^3 with (x, y) = (X/Z^2, Y/Z^3); scaled by Z^3: a*Y + b*X*Z*w + c*Z^3*w^3
-        const Fq xz0 = P0.X * P0.Z, z30 = P0.Z.sqr() * P0.Z, xz1 = P1.X * P1.Z, z31 = P1.Z.sqr() * P1.Z;
-        for (uint32_t li = t; li < N_LINES; li += PAIR_THREADS) {
-            const LineCoeff q0 = l_sg2[li], q1 = l_ng2[li];
-            Fq2 a0 = q0.a.scale(P0.Y), b0 = q0.b.scale(xz0), c0 = q0.c.scale(z30);
-            Fq2 a1 = q1.a.scale(P1.Y), b1 = q1.b.scale(xz1), c1 = q1.c.scale(z31);
-            // an identity point contributes the line value 1
-            if (skip0) { a0 = Fq2::one(); b0 = Fq2::zero(); c0 = Fq2::zero(); }
-            if (skip1) { a1 = Fq2::one(); b1 = Fq2::zero(); c1 = Fq2::zero(); }
-            // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
-            Fq2 a0a1 = a0 * a1, b0b1 = b0 * b1, c0c1 = c0 * c1;
-            Fq2 ab = (a0 + b0) * (a1 + b1) - a0a1 - b0b1;
-            Fq2 ac = (a0 + c0) * (a1 + c1) - a0a1 - c0c1;
-            Fq2 bc = (b0 + c0) * (b1 + c1) - b0b1 - c0c1;
-            s.line[li][0] = a0a1 + c0c1.mul_xi(); s.line[li][1] = ab; s.line[li][2] = b0b1; s.line[li][3] = ac; s.line[li][4] = bc;
-            s.line[li][5] = Fq2::zero();
-        }
-    }
-    if (t < 6) {
-        Coef c; c.c0 = t == 0 ? Fq::one() : Fq::zero(); c.c1 = Fq::zero(); c.n1 = Fq::zero();
-        s.reg[0][t] = c;
-    }
-    for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
-    if (t == 0) s.prod[36] = Fq2::zero();
-    __syncthreads();
-    uint32_t w_next = s.prog[0];
-    for (uint32_t pc = 0; pc < n_ops; ++pc) {
-        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_next);   // uniform: decoded on the scalar unit
-        w_next = s.prog[pc + 1 < n_ops ? pc + 1 : pc];   // read while this operation runs (k_pairing2: 0.79 -> 0.75 ms for the same change)
-        const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
-        if (op <= P_MULL) {
-            pair_products(op, ra, rb, s.line, s.reg, s.prod, t);
-            __syncthreads();
-            // ---- fold
-            if (t < 72) fq12_fold(s.prod, s.reg[rd], t);
-            __syncthreads();
-        } else if (op == P_CHECK) {
-            if (t == 0) ok[chk] = pair_in_fq_star(s.reg[ra]) ? 1u : 0u;
-        } else {
-            pair_coefficients(op, rd, ra, s.reg, consts, t);
-            __syncthreads();
-        }
-    }
-}
-
 // ---- k_pairing2: two operation streams per check (pairing_program2), 256 threads, group g = t / 128 executes column g of every step;
 // the line products always come from k_pair_lines.
 //
-// A product is ONE phase here (round 3; k_pairing above keeps the two-phase form: 72 dot2 lanes, LDS, barrier, fold lanes, barrier —
-// measured inside this kernel at 2390 + 80 + 2650 + 70 cycles per step, the fold the larger half).  The result's coordinate
+// A product is ONE phase (round 3; until then: 72 dot2 lanes, LDS, barrier, fold lanes, barrier — measured inside this kernel at
+// 2390 + 80 + 2650 + 70 cycles per step, the fold the larger half; k_pair_lines' tree still has that form).  The result's coordinate
 // (k, re / im) is a sum of six Fq2-product coordinates, a_i * b_j over i + j = k and xi a_i * b_j over i + j = k + 6, i.e. of twelve Fq
 // products.  EIGHT LANES own one output: lane i of the group computes term i as the 18-limb integer a_i0 B0 + a_i1 B1 WITHOUT a
 // reduction (162 multiply-adds, one carry sweep), the eight lanes add their limbs with three DPP steps (quad_perm, quad_perm,
@@ -612,7 +487,65 @@ __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, co
         if (op >= P_SQR && op <= P_MULL) pair_step6(op, rd, ra, rb, s.line, s.reg, tl);
         else if (op == P_CHECK) { if (tl == 0) ok[chk] = pair_in_fq_star6(s.reg[ra]) ? 1u : 0u; }
         else if (op) pair_coefficients6(op, rd, ra, s.reg, consts, tl);
-        __syncthreads();   // the one barrier of a step: a product's destination is a register nothing in its step reads (pairing_program2)
+        __syncthreads();   // the one barrier of a step: a product's destination is a register nothing in its step reads (pair_rename_registers)
+    }
+}
+
+// ---- k_pairing: ONE operation stream per check, two waves (a launch of more than 64 groups, SingleStrategy's one check per proof,
+// h2v_pairing_check, the single-stream form of a split check): the same one-phase product step and six-form registers as k_pairing2.
+// The lines come ready from k_pair_lines (`pre`, one merged line product per iteration) or are evaluated here at the two whole points
+// (all H2V_PAIRING_LINES of them, two sparse values multiplied per line).
+struct alignas(16) PairShared1 {
+    Fq2 line[N_LINES][6];
+    Coef6 reg[PAIR1_REGS][6];
+    uint32_t prog[PAIR_MAX_OPS];
+};
+__global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict__ pairs, uint32_t n, const LineCoeff* __restrict__ l_sg2,
+                                                          const LineCoeff* __restrict__ l_ng2, const PairingConsts* __restrict__ consts,
+                                                          const uint32_t* __restrict__ prog, uint32_t n_ops, const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
+    __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
+    extern __shared__ uint4 pair1_lds[];
+    PairShared1& s = *reinterpret_cast<PairShared1*>(pair1_lds);
+    const uint32_t chk = blockIdx.x, t = threadIdx.x;
+    if (chk >= n) return;
+    if (pre) {
+        // the steps' line products come ready from k_pair_lines (a check over split accumulators: 2 * parts lines per step)
+        const uint4* src = reinterpret_cast<const uint4*>(pre + (size_t)chk * PAIR_ITERS * 6);
+        uint4* dst = reinterpret_cast<uint4*>(&s.line[0][0]);
+        for (uint32_t k = t; k < PAIR_ITERS * 6 * sizeof(Fq2) / 16; k += PAIR_THREADS) dst[k] = src[k];
+    } else {
+        const G1J P0 = pairs[2 * chk], P1 = pairs[2 * chk + 1];
+        const bool skip0 = P0.is_identity(), skip1 = P1.is_identity();
+        // line l(P) = a*y + b*x*w + c*w^3 with (x, y) = (X/Z^2, Y/Z^3); scaled by Z^3: a*Y + b*X*Z*w + c*Z^3*w^3
+        const Fq xz0 = P0.X * P0.Z, z30 = P0.Z.sqr() * P0.Z, xz1 = P1.X * P1.Z, z31 = P1.Z.sqr() * P1.Z;
+        for (uint32_t li = t; li < N_LINES; li += PAIR_THREADS) {
+            const LineCoeff q0 = l_sg2[li], q1 = l_ng2[li];
+            Fq2 a0 = q0.a.scale(P0.Y), b0 = q0.b.scale(xz0), c0 = q0.c.scale(z30);
+            Fq2 a1 = q1.a.scale(P1.Y), b1 = q1.b.scale(xz1), c1 = q1.c.scale(z31);
+            // an identity point contributes the line value 1
+            if (skip0) { a0 = Fq2::one(); b0 = Fq2::zero(); c0 = Fq2::zero(); }
+            if (skip1) { a1 = Fq2::one(); b1 = Fq2::zero(); c1 = Fq2::zero(); }
+            // (a0 + b0 w + c0 w^3)(a1 + b1 w + c1 w^3) = (a0a1 + xi c0c1) + (a0b1 + b0a1) w + b0b1 w^2 + (a0c1 + c0a1) w^3 + (b0c1 + c0b1) w^4
+            Fq2 a0a1 = a0 * a1, b0b1 = b0 * b1, c0c1 = c0 * c1;
+            Fq2 ab = (a0 + b0) * (a1 + b1) - a0a1 - b0b1;
+            Fq2 ac = (a0 + c0) * (a1 + c1) - a0a1 - c0c1;
+            Fq2 bc = (b0 + c0) * (b1 + c1) - b0b1 - c0c1;
+            s.line[li][0] = a0a1 + c0c1.mul_xi(); s.line[li][1] = ab; s.line[li][2] = b0b1; s.line[li][3] = ac; s.line[li][4] = bc;
+            s.line[li][5] = Fq2::zero();
+        }
+    }
+    if (t < 36) s.reg[0][t / 6].f[t % 6] = coef_form(t < 6 ? Fq::one() : Fq::zero(), Fq::zero(), t % 6);   // register 0 (f) starts at one
+    for (uint32_t k = t; k < n_ops; k += PAIR_THREADS) s.prog[k] = prog[k];
+    __syncthreads();
+    uint32_t w_next = s.prog[0];
+    for (uint32_t pc = 0; pc < n_ops; ++pc) {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_next);   // uniform: decoded on the scalar unit
+        w_next = s.prog[pc + 1 < n_ops ? pc + 1 : pc];   // read while this operation runs
+        const uint32_t op = w & 255u, rd = (w >> 8) & 255u, ra = (w >> 16) & 255u, rb = w >> 24;
+        if (op <= P_MULL) pair_step6(op, rd, ra, rb, s.line, s.reg, t);
+        else if (op == P_CHECK) { if (t == 0) ok[chk] = pair_in_fq_star6(s.reg[ra]) ? 1u : 0u; }
+        else pair_coefficients6(op, rd, ra, s.reg, consts, t);
+        __syncthreads();
     }
 }
 
@@ -716,10 +649,18 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
     if (t < 6) out[((size_t)chk * PAIR_ITERS + it) * 6 + t] = Fq2{el(cur)[0][t].c0, el(cur)[0][t].c1};
 }
 
+// k_pairing's LDS (70 KB: 102 lines, 19 six-form registers, the table) is above the 64 KB a kernel gets without asking; per device, once
+static int pair1_lds_grant() {
+    static_assert(sizeof(PairShared1) <= 80 * 1024, "two workgroups of k_pairing per CU");
+    H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PairShared1)));
+    return 0;
+}
 int pairing_check_enqueue(hipStream_t s, const PairingDevice& pd, const G1J* d_pairs, uint32_t n, uint32_t* d_ok) {
     if (!n) return 0;
     if (!pd.prog || pd.n_ops > PAIR_MAX_OPS) { set_last_error("pairing: operation table missing or too long"); return H2V_ERR_BAD_ARGUMENT; }
-    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, (const Fq2*)nullptr, d_ok);
+    int rc = pair1_lds_grant();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), sizeof(PairShared1), s, d_pairs, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog, pd.n_ops, (const Fq2*)nullptr, d_ok);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -743,7 +684,10 @@ int pairing_check_split_enqueue(hipStream_t s, PairingDevice& pd, const G1JSlot*
     hipLaunchKernelGGL(k_pair_lines, dim3(PAIR_ITERS, n), dim3(PL_THREADS), 0, s, d_ready, parts, tab, its, lines);
     // (one_stream: h2v_tuning.pairing_one_stream — the single-stream table over the same lines)
     if (pd.prog2 && !one_stream) hipLaunchKernelGGL(k_pairing2, dim3(n), dim3(2 * PAIR_THREADS), 0, s, n, pd.consts, reinterpret_cast<const uint2*>(pd.prog2), pd.n_steps2, (const Fq2*)lines, d_ok);
-    else hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), 0, s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog_merged, pd.n_ops_merged, (const Fq2*)lines, d_ok);
+    else {
+        if ((rc = pair1_lds_grant())) return rc;
+        hipLaunchKernelGGL(k_pairing, dim3(n), dim3(PAIR_THREADS), sizeof(PairShared1), s, (const G1J*)nullptr, n, pd.l_sg2, pd.l_ng2, pd.consts, pd.prog_merged, pd.n_ops_merged, (const Fq2*)lines, d_ok);
+    }
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

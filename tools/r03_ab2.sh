@@ -1,6 +1,6 @@
 # forced Fr-program forms at the driver's command
 mkdir -p gpurun_out/r03_ab2
-for t in "none" "frvm_streams=2" "frvm_streams=3" "frvm_streams=4" "frvm_streams=1" "frvm_streams=3,frvm_lds_kb=78" "frvm_streams=2,frvm_lds_kb=78" "pairing_one_stream=1" "msm_parts=1" "msm_parts=3"; do
+for t in "none" "frvm_streams=4,frvm_lds_kb=78" "frvm_streams=4,frvm_lds_kb=64" "frvm_streams=4,frvm_lds_kb=100" "frvm_streams=4,frvm_lds_kb=36"; do
   f=gpurun_out/r03_ab2/$(echo $t | tr '=,' '__').json
   case $t in none*) T="";; *) T="--tuning $t";; esac
   timeout -k 10 120 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-reupload-leg --no-extra-legs $T > $f 2> ${f%.json}.err || exit 1
