@@ -230,7 +230,8 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
         if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(sm, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
         else if ((rc = multipliers_enqueue(sm, b->tail, b->n_tail, n, G, b->mult))) return rc;
-        H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, sm));  // the program writes only the slots the left channel uses
+        // the program writes only the slots the left channel uses; with ONE left term per proof the MSM reads exactly those (a strided problem, below)
+        if (!(pl.left_term_order.size() == 1 && !pl.left_term_order[0].first)) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, sm));
         H2V_HIP_CHECK(hipEventRecord(b->ev_join0, sm));
         H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join0, 0));   // joined before the Fr program reads them
     }
@@ -260,9 +261,17 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         const uint32_t np = pl.n_points;
         for (uint32_t g = 0; g < G; ++g) {
             const size_t first = (size_t)g * gs * np;
-            pr.p.push_back(MsmProblem(b->left_scal + first * 8, b->pts + first, b->acc + 2 * g, 8, 1, gs * np));
-            pr.p.back().phi = b->phi + first;
-            pr.p.back().nnz = gs * (uint32_t)pl.left_term_order.size();   // the program writes only these slots, the rest stay zero
+            if (pl.left_term_order.size() == 1 && !pl.left_term_order[0].first) {
+                // SHPLONK: one left term per proof (its h2): the problem is that slot of every proof — a strided view of gs terms, not the
+                // group's gs * np slots with gs of them non-zero (msm_glv_prep wrote twelve zero words for each of the other slots)
+                const size_t at = first + pl.left_term_order[0].second;
+                pr.p.push_back(MsmProblem(b->left_scal + at * 8, b->pts + at, b->acc + 2 * g, 8 * np, np, gs));
+                pr.p.back().phi = b->phi + at;
+            } else {
+                pr.p.push_back(MsmProblem(b->left_scal + first * 8, b->pts + first, b->acc + 2 * g, 8, 1, gs * np));
+                pr.p.back().phi = b->phi + first;
+                pr.p.back().nnz = gs * (uint32_t)pl.left_term_order.size();   // the program writes only these slots, the rest stay zero
+            }
             pr.p.push_back(MsmProblem(b->msm_scal + first * 8, b->pts + first, b->acc + 2 * g + 1, 8, 1, gs * np,
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
             pr.p.back().phi = b->phi + first; pr.p.back().phi2 = b->phi + (size_t)n * np;
