@@ -1,4 +1,5 @@
-// Micro-benchmark of the wave-parallel Fq12 product used by csrc/pairing.hip.
+// Micro-benchmark of the wave-parallel Fq12 product as csrc/pairing.hip had it in round 1 (36 Fq2::mul lanes + 6 fold lanes); the
+// kernels now run a one-phase product (eight lanes per output, one reduction per output: DESIGN.md §4).  Kept for the record.
 // Build: hipcc -O3 --offload-arch=gfx950 -I halo2_verifier_amd/csrc tools/wmul_microbench.hip -o tools/wmul_microbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,7 +10,7 @@ namespace h2v { void set_last_error(const std::string&) {} }
 
 struct Sh { Fq2 prod[36]; Fq2 f[6], g[6]; };
 
-__device__ __forceinline__ void wmul_a(Sh& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {  // as in pairing.hip
+__device__ __forceinline__ void wmul_a(Sh& s, Fq2* dst, const Fq2* x, const Fq2* y, uint32_t lane) {  // as in round 1's pairing.hip
     if (lane < 36) s.prod[lane] = Fq2::mul(x[lane / 6], y[lane % 6]);
     __syncthreads();
     if (lane < 6) {
