@@ -4,19 +4,19 @@
 // A pairing is a strictly sequential chain of ~470 Fq12 operations (Miller loop over 6x+2, then the final
 // exponentiation); a batch ends with exactly one of them, so what counts is the LATENCY of one Fq12 operation.
 //
-// Two waves per check.  An Fq12 element lives in LDS as six Fq2 coefficients of Fq2[w]/(w^6 - xi), each stored with its
-// negated imaginary part alongside (c0, c1, -c1).  One product has two phases:
-//   products  lane (i, j, coordinate) computes ONE coordinate of a_i * b_j as a single-pass sum of two Fq products with one
-//             shared Montgomery reduction (Fp::dot2_inl):  re = a0 b0 + a1 (-b1),  im = a0 b1 + a1 b0 — the stored -c1 means
-//             no arithmetic at all comes before the multiply.  72 lanes for a general product, 42 for a squaring (the 21
-//             distinct a_i a_j), 60 for a product with a Miller line (its w^5 coefficient is zero): always ONE pass.
-//   fold      18 outputs, one per (coefficient, re / im / -im), three lanes each: plain limb sums of the partial products; the
-//             w^6 = xi = 9 + u reduction is applied HERE as integer weights on the sums (re: low + 9 hi_re - hi_im, im: low +
-//             9 hi_im + hi_re), brought below 2p by Fp::from_wide — no Montgomery pass, no modular additions.
-// Round 1 applied xi to an operand inside every product lane (two from_wide per lane: as many instructions as the multiply
-// itself) and ran through ~100 call sites with spills around each; here the whole pairing is a TABLE of ~470 operations
-// (built once per context on the host: Miller loop, easy part, the x-power chain of the hard part) interpreted by one loop
-// whose body holds a single inlined product and a single inlined fold.
+// The whole pairing is a TABLE of ~470 Fq12 operations (built once per context on the host: Miller loop, easy part, the x-power chain
+// of the hard part) interpreted by one loop; an Fq12 element lives in LDS as six Fq2 coefficients of Fq2[w]/(w^6 - xi).
+//   k_pairing    one operation stream, two waves per check;  k_pairing2: two streams side by side, four waves per check (the checks
+//                over split accumulators: every launch of at most 64 groups).  Both run the same step:
+//   pair_step6   a product in ONE phase: eight lanes per output coordinate, each an unreduced 18-limb a0 B0 + a1 B1, the limbs added
+//                across the lanes by DPP, one Montgomery reduction per output; every register coefficient is kept in six forms
+//                (c0, c1, -c1, xi c and its negated imaginary part) so that no term needs a subtraction or a multiplication by xi;
+//                one barrier per step, products never in place (pair_rename_registers).  Details above k_pairing2.
+//   k_pair_lines the line products of every Miller iteration, all iterations at once, before the sequential part (it still uses the
+//                older two-phase product: dot2 lanes into LDS, then fold lanes — fq12_fold below).
+// History: round 1 applied xi to an operand inside every product lane and ran through ~100 call sites with spills around each; round 2
+// made the table and the two-phase product (72 dot2 lanes, 18 fold outputs); round 3 measured that step at 2390 + 2650 cycles plus two
+// barriers and replaced it.
 //
 // The G2 side is constant per context, so its Miller-loop line coefficients are precomputed once on the host
 // (g2_prepare); the lanes evaluate them at the two G1 points up front, all lines in parallel, into LDS.
