@@ -56,7 +56,15 @@ namespace h2v {
 #define MSM_CHUNK_MAX 64u
 #define MSM_ACC_LANES_PER_ROUND 196608u   // 3 waves per SIMD x 1024 SIMDs x 64 lanes (msm_accumulate: 156 VGPRs since its slow path left the kernel)
 // (R = lanes per round: MSM_ACC_LANES_PER_ROUND, or 4 waves per SIMD's worth when the launch runs that variant — MsmSeg::lanes_round)
+// (A SHORT list — a batch of up to ~256 proofs; the MSM of ONE proof is ~900 entries — is cut into chunks of MSM_CHUNK_SMALL: 16 entries
+// on each of 57 lanes took 0.21 ms where 4 entries on 228 lanes take 0.12.  Not beyond: shorter chunks spread a bucket over more of
+// them, and from ~512 proofs on the longer fix-up chains of the top window's buckets cost more than the accumulation gains — one
+// batch of 1 / 16 / 256 / 512 / 1024 proofs: 1.43 / 1.40 / 1.49 / 1.66 / 1.83 ms with chunks of 4 throughout, 1.49 / 1.45 / 1.57 /
+// 1.55 / 1.67 ms with chunks of 16, tools/batch_latency_probe.py.)
+#define MSM_CHUNK_SMALL 4u
+#define MSM_SHORT_LIST 98304u
 __host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E, uint32_t R) {
+    if (E <= MSM_SHORT_LIST) return MSM_CHUNK_SMALL;
     if (E <= R * MSM_CHUNK_MIN) return MSM_CHUNK_MIN;
     const uint32_t k = (uint32_t)(((uint64_t)E + (uint64_t)R * MSM_CHUNK_MAX - 1) / ((uint64_t)R * MSM_CHUNK_MAX));
     const uint32_t c = (uint32_t)(((uint64_t)E + (uint64_t)k * R - 1) / ((uint64_t)k * R));
@@ -66,7 +74,8 @@ __host__ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t E, uint32_t 
 // lanes ceil(E / msm_chunk_len(E)) stay within k whole rounds, k = the rounds of the bound itself
 static inline uint32_t msm_accumulate_blocks(size_t max_entries, size_t R) {
     size_t lanes;
-    if (max_entries <= R * MSM_CHUNK_MIN) lanes = (max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
+    if (max_entries <= R * MSM_CHUNK_MIN)   // E <= max_entries: chunks of 16 — or of 4 while E <= MSM_SHORT_LIST
+        lanes = std::max<size_t>((max_entries + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN, (std::min<size_t>(max_entries, MSM_SHORT_LIST) + MSM_CHUNK_SMALL - 1) / MSM_CHUNK_SMALL);
     else lanes = (max_entries + R * MSM_CHUNK_MAX - 1) / (R * MSM_CHUNK_MAX) * R;
     return (uint32_t)(((lanes + 63) / 64 + 1 + 7) / 8 * 8);
 }
@@ -157,8 +166,10 @@ int MsmWorkspace::alloc(uint32_t max_terms, uint32_t max_problems, uint32_t max_
     H2V_HIP_CHECK(hipMalloc(&problems, (size_t)cap_problems * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&parents, (size_t)cap_parents * sizeof(MsmProblem)));
     H2V_HIP_CHECK(hipMalloc(&block_sums, (mb / 1024 + 2) * 4));
-    H2V_HIP_CHECK(hipMalloc(&partial, (cap_list / MSM_CHUNK_MIN + 1) * 2 * sizeof(G1JSlot)));
-    H2V_HIP_CHECK(hipMalloc(&redo, (cap_list / MSM_CHUNK_MIN + 1) * 4));
+    // chunks of a launch at most: cap_list / 16, or (short lists, msm_chunk_len) a quarter of up to MSM_SHORT_LIST entries
+    const size_t max_chunks = std::max<size_t>(cap_list / MSM_CHUNK_MIN + 1, std::min<size_t>(cap_list, MSM_SHORT_LIST) / MSM_CHUNK_SMALL + 1);
+    H2V_HIP_CHECK(hipMalloc(&partial, max_chunks * 2 * sizeof(G1JSlot)));
+    H2V_HIP_CHECK(hipMalloc(&redo, max_chunks * 4));
     H2V_HIP_CHECK(hipMalloc(&glv, (cap_list / 2 + 1) * 4));   // digit table: one word per (term, window)
     H2V_HIP_CHECK(hipMalloc(&phi_pts, ((size_t)cap_terms + 1) * sizeof(G1A)));
     H2V_HIP_CHECK(hipMalloc(&seg_total, ((size_t)128 * cap_problems + 2) * 4));
