@@ -254,13 +254,23 @@ __global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __r
     const unsigned long long pers0 = 0x72542d326f6c6148ULL, pers1 = 0x7470697263736e61ULL;  // "Halo2-Tr" "anscript" little endian
     unsigned long long h0 = BLAKE_IV[r] ^ (r == 0 ? 0x01010040ULL : 0ULL), h1 = BLAKE_IV[4 + r] ^ (r == 2 ? pers0 : (r == 3 ? pers1 : 0ULL));
     uint32_t blk = 0;
+    // the lane's four words of the block that is needed next, fetched while the block before it is compressed (a load per block on the
+    // critical path was ~1 us of every one of the ~18 compressions of a proof)
+    const uint32_t n_blocks = stream_words / 16;
+    unsigned long long pf[4];
+    uint32_t pf_blk = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) pf[j] = words[4 * r + j];
     for (uint32_t q = 0; q < n_squeeze; ++q) {
         const uint32_t len = squeeze_at[q];  // >= 1
         const uint32_t last_blk = (len - 1) / 128;
         for (; blk < last_blk; ++blk) {
             __syncthreads();
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) msg[4 * r + j] = words[(size_t)blk * 16 + 4 * r + j];
+            for (uint32_t j = 0; j < 4; ++j) msg[4 * r + j] = pf_blk == blk ? pf[j] : words[(size_t)blk * 16 + 4 * r + j];
+            pf_blk = blk + 1 < n_blocks ? blk + 1 : blk;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) pf[j] = words[(size_t)pf_blk * 16 + 4 * r + j];
             __syncthreads();
             blake2b_compress_quad(h0, h1, msg, sig, (unsigned long long)(blk + 1) * 128, false, r);
         }
@@ -268,7 +278,7 @@ __global__ void __launch_bounds__(64) k_transcript(const unsigned long long* __r
         __syncthreads();
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            unsigned long long w = words[(size_t)last_blk * 16 + 4 * r + j];
+            unsigned long long w = pf_blk == last_blk ? pf[j] : words[(size_t)last_blk * 16 + 4 * r + j];   // (stays prefetched: the stream goes on inside this block)
             const uint32_t lo = 8 * (4 * r + j);
             if (lo >= rem) w = 0;
             else if (lo + 8 > rem) w &= (1ULL << (8 * (rem - lo))) - 1;
