@@ -877,13 +877,27 @@ __global__ void __launch_bounds__(MSM_WIN_THREADS) msm_window(const G1JSlot* __r
         if (t == 0 && live) window_sums[widx] = *sum;
         return;
     }
-    red[t] = *sum;
-    __syncthreads();
-    for (uint32_t d = T / 2; d > 0; d >>= 1) {
-        if (t < d) g1_add_to(&red[t], &red[t], &red[t + d]);
-        __syncthreads();
+    // several waves per window: the same butterfly inside every wave (no barrier: the tree over all T lanes through LDS was seven
+    // additions with a workgroup barrier each, 200 000 cycles where the additions alone are 147 000), then the waves' leaders through LDS
+    const uint32_t W = T < 64u ? T : 64u;  // lanes of this window inside one wave (T is a power of two)
+    for (uint32_t d = W / 2; d > 0; d >>= 1) {
+        const G1J mine_sum = *sum;
+        G1J other;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&mine_sum);
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 64);
+        if ((t & (W - 1)) + d >= W) other = G1J::identity();
+        *scaled = other;
+        g1_add_to(sum, sum, scaled);
     }
-    if (t == 0 && live) window_sums[widx] = red[0];
+    __syncthreads();                       // every lane is done with its `scaled` slot: the first T / 64 of them now carry the waves' sums
+    if ((t & (W - 1)) == 0) red[t >> 6] = *sum;
+    __syncthreads();
+    if (t == 0) {
+        for (uint32_t wv = 1; wv < (T >> 6); ++wv) g1_add_to(&red[0], &red[0], &red[wv]);
+        if (live) window_sums[widx] = red[0];
+    }
 }
 
 // ---- msm_final: Horner over the windows — c doublings and one addition per window, ~130 dependent group operations, nothing
