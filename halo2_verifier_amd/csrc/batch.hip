@@ -313,8 +313,9 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     }
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork, s));
     H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork, 0));
-    if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split))) return rc;   // acc <- the whole points
-    if ((rc = point_to_bytes_enqueue(b->aux, b->acc, b->out_bytes, b->out_ident, 2 * G))) return rc;
+    // (beside the pairing: kept off the pairing workgroups' CUs by an LDS request, internal.h)
+    if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split, H2V_AUX_LDS_RESERVE))) return rc;   // acc <- the whole points
+    if ((rc = point_to_bytes_enqueue(b->aux, b->acc, b->out_bytes, b->out_ident, 2 * G, H2V_AUX_LDS_RESERVE))) return rc;
     H2V_HIP_CHECK(hipEventRecord(b->ev_join, b->aux));
     if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.ready, G, b->split.parts, b->split.shift, b->line_ws, b->ok, b->ctx->tuning.pairing_one_stream != 0))) return rc; }
     else if ((rc = pairing_check_enqueue(s, b->ctx->pairing, b->acc, G, b->ok))) return rc;

@@ -129,7 +129,13 @@ struct MsmWorkspace {
 // and *out is NOT written until msm_combine_enqueue (any stream ordered after `s`).  split->parts == 0 on return: the launch was
 // not cut (no terms, or a single window) and *out is written as without `split`.
 int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split = nullptr);
-int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp);
+int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp, size_t lds_reserve = 0);
+// `lds_reserve` (msm_combine_enqueue, point_to_bytes_enqueue): bytes of LDS the launch asks for without using them.  The two kernels run
+// on a batch's auxiliary stream BESIDE the pairing, as a handful of waves with a 0.3 ms chain of their own; where one of those waves
+// landed on a SIMD of a pairing workgroup (which issues at raised priority) it crawled — msm_combine_parts took 0.29 ms alone and up to
+// 0.53 ms beside k_pairing2, and the launch then waited for IT.  A workgroup that asks for more LDS than a CU has left beside a
+// k_pairing2 workgroup (160 KB - 58 KB) is never placed on such a CU, and its CU takes no pairing workgroup afterwards.
+#define H2V_AUX_LDS_RESERVE ((size_t)110 * 1024)
 int msm_enqueue(hipStream_t s, MsmWorkspace& ws, const uint32_t* d_scalars, const G1A* d_bases, uint32_t n, G1J* d_out);
 
 // ------------------------------------------------------------------ small helpers (util.hip)
@@ -138,7 +144,7 @@ int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, 
 // canonical 32-B scalars -> 8 x 32-bit words (validated < r); flags[i] = 1 when >= r
 int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
 // Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
-int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n);
+int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n, size_t lds_reserve = 0);
 // Sharded batches exchange H2V_ACC_RECORD_BYTES records per group: [failed, parts, shift, 0][left pieces][right pieces] (h2v.h).
 // export: d_out[g] <- the group's accumulators — pieces [(2g + side) * parts + j] if d_pieces, else the whole points d_acc[2g], [2g+1] —
 // and the number of non-zero statuses among the group's n / groups proofs

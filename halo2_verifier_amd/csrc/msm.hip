@@ -1160,9 +1160,10 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp) {
+int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp, size_t lds_reserve) {
     if (!sp.parts) return 0;
-    hipLaunchKernelGGL(msm_combine_parts, dim3((4 * sp.count + 63) / 64), dim3(64), 0, s, sp.pts, ws.final_problems, sp.count, sp.parts, sp.shift);
+    if (lds_reserve > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)msm_combine_parts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reserve));
+    hipLaunchKernelGGL(msm_combine_parts, dim3((4 * sp.count + 63) / 64), dim3(64), lds_reserve, s, sp.pts, ws.final_problems, sp.count, sp.parts, sp.shift);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -152,9 +152,10 @@ int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* 
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n) {
+int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n, size_t lds_reserve) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_point_to_bytes, dim3((n + 63) / 64), dim3(64), 0, s, d_in, d_out_xy64, d_is_identity, n);
+    if (lds_reserve > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_point_to_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reserve));
+    hipLaunchKernelGGL(k_point_to_bytes, dim3((n + 63) / 64), dim3(64), lds_reserve, s, d_in, d_out_xy64, d_is_identity, n);
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
