@@ -214,11 +214,14 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     int ev = 0;
     auto mark = [&]() { if (b->profiling >= 2) hipEventRecord(b->ev[ev], s); ++ev; };   // (an event record is a barrier packet: ~6 us of idle stream each)
     mark();
-    H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this launch (uploads) is visible to the auxiliary stream
     StageArgs g{n, &pl, pd, b->proofs, b->inst, b->pts, b->phi, b->ycanon, b->status, b->words, b->stream_words, b->chal};
     // stage 1: point decompression + canonicity checks (already on the stream, behind its chunked upload, after h2v_batch_upload_launch);
-    // stage 2: absorbed stream, Blake2b challenges, batch multipliers
-    if (!b->decompressed && (rc = decompress_stage_enqueue(s, g))) return rc;
+    // stage 2: absorbed stream, Blake2b challenges, batch multipliers.  The status words are cleared first, then the auxiliary stream is
+    // forked: the scalar canonicity check (proof bytes only) runs there beside the decompression, with the multipliers
+    const bool run_decompress = !b->decompressed;
+    if (run_decompress && (rc = decompress_begin_enqueue(s, g))) return rc;
+    H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this point (uploads, the cleared status words) is visible to the auxiliary stream
+    if (run_decompress && (rc = decompress_range_enqueue(s, g, 0, n))) return rc;
     b->decompressed = false;   // (a later h2v_batch_launch on the same upload runs the stage again: every launch does all of its work)
     mark();
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
@@ -226,6 +229,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     if (n) {
         H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork0, 0));
         hipStream_t sm = b->aux;
+        if (run_decompress && (rc = decompress_finish_enqueue(sm, g))) return rc;   // k_check_scalars
         // multipliers: suffix products of the uploaded draws — or, for a batch that is a non-contiguous subset of a larger
         // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
         if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(sm, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
