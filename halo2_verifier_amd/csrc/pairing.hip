@@ -276,6 +276,7 @@ std::vector<uint32_t> pairing_program2() {
     return steps;
 }
 
+// ---- k_pair_lines' product (the two-phase form: dot2 lanes into LDS, then these fold lanes); the sequential kernels use pair_step6 below
 struct Coef { Fq c0, c1, n1; };   // an Fq2 coefficient and the negated imaginary part: n1 = -c1
 
 // k-fold multiples of p on the limbs (offsets that keep the fold's integer combinations non-negative)
