@@ -41,5 +41,32 @@ for it in range(int(os.environ.get("SOAK_MSM", "60"))):
         scalars.append(k); bases.append(b)
     if ctx.msm_g1(scalars, bases) != oracle_lib.g1_msm(oracle, scalars, bases):
         bad += 1; print("MSM MISMATCH", it, n, pool, kind)
+# pairing verdicts (round 3: the kernels drop the final exponentiation's inversion and test membership in Fq*): SOAK_PAIR seeded cases —
+# relations that hold, near misses, identities on either side, equal and opposite points — against the oracle's textbook check
+import ctypes
+P_ORDER_CASES = int(os.environ.get("SOAK_PAIR", "600"))
+rnd = random.Random(2026)
+def oracle_check(l, r):
+    ok = ctypes.c_int(-1)
+    assert oracle.h2o_pairing_check(srs.params_raw, len(srs.params_raw), 1, l, r, ctypes.byref(ok)) == 0
+    return bool(ok.value)
+pair_bad = 0
+for it in range(P_ORDER_CASES):
+    m = rnd.randrange(1, 4)
+    idx = [rnd.randrange(0, 250) for _ in range(m)]
+    a = [rnd.randrange(1, R_MOD) for _ in range(m)]
+    left = oracle_lib.g1_msm(oracle, a, [pts[i] for i in idx])
+    right = oracle_lib.g1_msm(oracle, a, [pts[i + 1] for i in idx])
+    kind = it % 6
+    if kind == 1: right = oracle_lib.g1_msm(oracle, [(a[0] + 1) % R_MOD or 1] + a[1:], [pts[i + 1] for i in idx])
+    elif kind == 2: left, right = right, left
+    elif kind == 3: right = neg(right)
+    elif kind == 4: left = bytes(64) if it % 12 == 4 else left; right = bytes(64)
+    elif kind == 5: right = left
+    want, got = oracle_check(left, right), ctx.pairing_check(left, right)
+    if want != got:
+        pair_bad += 1; print("PAIRING MISMATCH case", it, kind, want, got)
+print("pairing verdicts:", P_ORDER_CASES, "cases, mismatches:", pair_bad)
+bad += pair_bad
 ctx.close()
 print("soak done, mismatches:", bad)
