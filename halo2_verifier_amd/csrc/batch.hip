@@ -240,28 +240,11 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join0, 0));   // joined before the Fr program reads them
     }
     mark();
-    FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
-               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval, b->guard_scal, (uint32_t)pl.guard_term_order.size()};
-    if (n && pl.wide_instances) {
-        Fr step = pl.omega;
-        for (int i = 0; i < 8; ++i) step = step.sqr();   // omega^256: a thread's stride through the column
-        const Fr step_inv = step.inv();
-        for (size_t q = 0; q < pl.inst_queries.size(); ++q) {
-            InstEvalArgs ia{b->inst, pl.n_instance_values, b->chal, pl.x_chal, n, pl.domain_k, pl.inst_queries[q].base, pl.inst_queries[q].len,
-                            pl.inst_queries[q].w_start, pl.omega, step, step_inv, pl.n_inv, b->insteval + q * (size_t)n, b->status};
-            if ((rc = instance_eval_enqueue(s, ia))) return rc;
-        }
-    }
-    a.force_streams = ctx->tuning.frvm_streams; a.force_lds_kb = ctx->tuning.frvm_lds_kb;
-    for (int k = 0; k < 3; ++k) { for (int q = 0; q < k + 2; ++q) { a.code_k[k][q] = pd->code_k[k][q]; a.n_code_k[k][q] = (uint32_t)pl.code_k[k][q].size(); } a.n_slots_k[k] = pl.n_slots_k[k]; }
-    if ((rc = frvm_enqueue(s, a, pl.n_slots))) return rc;
-    mark();
-    if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, G, b->msm_scal))) return rc; }
-    mark();
-    {   // both channels of every group in one set of launches: [2g] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points),
-        // [2g+1] right = the group's pooled Guard terms + its folded VK-wide bases.  Both index the same point array; unused
-        // slots have zero scalars and cost nothing.
-        MsmProblems pr;
+    // both channels of every group in one set of launches: [2g] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points),
+    // [2g+1] right = the group's pooled Guard terms + its folded VK-wide bases.  Both index the same point array; unused
+    // slots have zero scalars and cost nothing.  The descriptors are addresses and sizes: they go to the device in FRONT of the Fr program.
+    MsmProblems pr;
+    {
         const uint32_t np = pl.n_points;
         for (uint32_t g = 0; g < G; ++g) {
             const size_t first = (size_t)g * gs * np;
@@ -280,6 +263,28 @@ int launch_impl(h2v_batch* b, int with_pairing) {
                                       b->msm_scal + ((size_t)n * np + (size_t)g * pl.n_shared) * 8, b->pts + (size_t)n * np, n ? pl.n_shared : 0));
             pr.p.back().phi = b->phi + first; pr.p.back().phi2 = b->phi + (size_t)n * np;
         }
+    }
+    b->ws.tune = ctx->tuning;
+    if (n && (rc = msm_prepare_problems(s, b->ws, pr))) return rc;
+    FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
+               b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval, b->guard_scal, (uint32_t)pl.guard_term_order.size()};
+    if (n && pl.wide_instances) {
+        Fr step = pl.omega;
+        for (int i = 0; i < 8; ++i) step = step.sqr();   // omega^256: a thread's stride through the column
+        const Fr step_inv = step.inv();
+        for (size_t q = 0; q < pl.inst_queries.size(); ++q) {
+            InstEvalArgs ia{b->inst, pl.n_instance_values, b->chal, pl.x_chal, n, pl.domain_k, pl.inst_queries[q].base, pl.inst_queries[q].len,
+                            pl.inst_queries[q].w_start, pl.omega, step, step_inv, pl.n_inv, b->insteval + q * (size_t)n, b->status};
+            if ((rc = instance_eval_enqueue(s, ia))) return rc;
+        }
+    }
+    a.force_streams = ctx->tuning.frvm_streams; a.force_lds_kb = ctx->tuning.frvm_lds_kb;
+    for (int k = 0; k < 3; ++k) { for (int q = 0; q < k + 2; ++q) { a.code_k[k][q] = pd->code_k[k][q]; a.n_code_k[k][q] = (uint32_t)pl.code_k[k][q].size(); } a.n_slots_k[k] = pl.n_slots_k[k]; }
+    if ((rc = frvm_enqueue(s, a, pl.n_slots))) return rc;
+    mark();
+    if (n) { if ((rc = fold_shared_enqueue(s, b->shared, n, pl.n_points, pl.n_shared, G, b->msm_scal))) return rc; }
+    mark();
+    {
         b->ws.profile = b->profiling >= 1; b->ws.profile_recorded = false;
         // A launch leaves the accumulators in pieces (MsmSplit): its own pairing checks take the pieces and the whole points are put
         // together beside them (close_enqueue); a launch without a pairing (a shard) exports the pieces, the folded pairing takes them,

@@ -102,6 +102,7 @@ struct MsmWorkspace {
     G1JSlot* bucket_pts = nullptr;  // [problems * windows * buckets]
     G1JSlot* window_sums = nullptr; // [problems * windows]
     G1JSlot* pieces = nullptr;      // [2][problems * MSM_MAX_PARTS] partial Horner sums (MsmSplit): Jacobian, then line-ready
+    std::vector<MsmProblem> prepared; // the caller's problems msm_prepare_problems uploaded ahead of the next msm_enqueue_multi (empty: none)
     MsmProblem* problems = nullptr;  // [cap_problems] descriptors of the launch in flight (sub-problems when large problems are cut)
     MsmProblem* parents = nullptr;   // [cap_parents] the caller's problems when they were cut
     G1JSlot* merged_sums = nullptr;  // [cap_parents * 128] window sums of the caller's problems, merged over their sub-problems
@@ -130,6 +131,8 @@ struct MsmWorkspace {
 // not cut (no terms, or a single window) and *out is written as without `split`.
 int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split = nullptr);
 int msm_combine_enqueue(hipStream_t s, MsmWorkspace& ws, const MsmSplit& sp, size_t lds_reserve = 0);
+// optional: the descriptors of the NEXT msm_enqueue_multi on this workspace, sent ahead on the same stream (msm.hip)
+int msm_prepare_problems(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr);
 // `lds_reserve` (msm_combine_enqueue, point_to_bytes_enqueue): bytes of LDS the launch asks for without using them.  The two kernels run
 // on a batch's auxiliary stream BESIDE the pairing, as a handful of waves with a 0.3 ms chain of their own; where one of those waves
 // landed on a SIMD of a pairing workgroup (which issues at raised priority) it crawled — msm_combine_parts took 0.29 ms alone and up to

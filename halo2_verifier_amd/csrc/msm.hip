@@ -1036,42 +1036,79 @@ static void msm_upload_problems(hipStream_t s, const std::vector<MsmProblem>& v,
     }
 }
 
-int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split) {
-    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; split->ready = nullptr; }
+// the shape of a launch: the caller's problems as they are, or cut into sub-problems
+struct MsmLaunchShape { std::vector<MsmProblem> launch_p, parents_p; bool cut = false; uint32_t nmax = 0; size_t total = 0, total_nz = 0; };
+static int msm_shape(const MsmWorkspace& ws, const MsmProblems& pr, MsmLaunchShape& L) {
     const uint32_t n_callers = (uint32_t)pr.p.size();
-    if (n_callers == 0) return 0;
     if (n_callers > MSM_MAX_PROBLEMS || n_callers > std::max(ws.cap_problems, ws.cap_parents)) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
-    uint32_t nmax = 0; size_t total = 0, total_nz = 0;
-    for (uint32_t q = 0; q < n_callers; ++q) { nmax = std::max(nmax, pr.p[q].n); total += pr.p[q].n; total_nz += pr.p[q].nnz ? std::min(pr.p[q].nnz, pr.p[q].n) : pr.p[q].n; }
+    for (uint32_t q = 0; q < n_callers; ++q) { L.nmax = std::max(L.nmax, pr.p[q].n); L.total += pr.p[q].n; L.total_nz += pr.p[q].nnz ? std::min(pr.p[q].nnz, pr.p[q].n) : pr.p[q].n; }
     // A problem too large for the per-window LDS sort is cut into equal sub-problems that are not: the launch then looks like a
     // grouped batch (LDS sort, short buckets, many narrow window reductions side by side) — for one 8192-proof batch the uncut form
     // spent 0.77 ms in the global counting sort, 0.59 in the fix-up and 0.52 in two 4096-bucket window reductions.  The window sums
     // of a problem's sub-problems are added up (msm_merge_windows) before the Horner.
-    std::vector<MsmProblem> launch_p, parents_p;
-    bool cut = false;
-    if (nmax > MSM_LDS_SORT_MAX_TERMS && !ws.tune.msm_no_term_split) {
+    if (L.nmax > MSM_LDS_SORT_MAX_TERMS && !ws.tune.msm_no_term_split) {
         size_t subs = 0;
         for (uint32_t q = 0; q < n_callers; ++q) subs += msm_subproblems(pr.p[q].n);
-        cut = subs <= ws.cap_problems && subs <= MSM_MAX_PROBLEMS && n_callers <= ws.cap_parents;
+        L.cut = subs <= ws.cap_problems && subs <= MSM_MAX_PROBLEMS && n_callers <= ws.cap_parents;
     }
-    if (cut) {
+    if (L.cut) {
         for (uint32_t q = 0; q < n_callers; ++q) {
             const MsmProblem& c = pr.p[q];
             const uint32_t k = msm_subproblems(c.n), per = (c.n + k - 1) / k;
             MsmProblem parent = c;
-            parent.sub_first = (uint32_t)launch_p.size(); parent.sub_count = k;
-            for (uint32_t i = 0; i < k; ++i) { const uint32_t first = std::min(c.n, i * per); launch_p.push_back(msm_problem_slice(c, first, std::min(per, c.n - first))); }
-            parents_p.push_back(parent);
+            parent.sub_first = (uint32_t)L.launch_p.size(); parent.sub_count = k;
+            for (uint32_t i = 0; i < k; ++i) { const uint32_t first = std::min(c.n, i * per); L.launch_p.push_back(msm_problem_slice(c, first, std::min(per, c.n - first))); }
+            L.parents_p.push_back(parent);
         }
-        nmax = 0;
-        for (const MsmProblem& q : launch_p) nmax = std::max(nmax, q.n);
-        msm_upload_problems(s, parents_p, false, ws.parents);
+        L.nmax = 0;
+        for (const MsmProblem& q : L.launch_p) L.nmax = std::max(L.nmax, q.n);
     } else {
         if (n_callers > ws.cap_problems) { set_last_error("msm_enqueue_multi: too many problems"); return H2V_ERR_BAD_ARGUMENT; }
-        launch_p = pr.p;
+        L.launch_p = pr.p;
+    }
+    return 0;
+}
+static bool msm_same_problems(const std::vector<MsmProblem>& a, const std::vector<MsmProblem>& b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const MsmProblem &x = a[i], &y = b[i];
+        if (x.scalars != y.scalars || x.bases != y.bases || x.out != y.out || x.sstride != y.sstride || x.bstride != y.bstride || x.n != y.n || x.n1 != y.n1 ||
+            x.scalars2 != y.scalars2 || x.bases2 != y.bases2 || x.phi != y.phi || x.phi2 != y.phi2 || x.nnz != y.nnz) return false;
+    }
+    return true;
+}
+// The problem descriptors depend on addresses and sizes only: a caller that knows them before the scalars exist (the batch verifier,
+// while the Fr program still runs) hands them to the device early — the same stream, in front of the kernel that produces the scalars —
+// and msm_enqueue_multi finds them there (two 5 us launches and a kernel boundary off the chain behind the Fr program).
+int msm_prepare_problems(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
+    ws.prepared.clear();
+    if (pr.p.empty()) return 0;
+    MsmLaunchShape L;
+    int rc = msm_shape(ws, pr, L);
+    if (rc) return rc;
+    if (L.cut) msm_upload_problems(s, L.parents_p, false, ws.parents);
+    msm_upload_problems(s, L.launch_p, true, ws.problems);
+    H2V_HIP_CHECK(hipGetLastError());
+    ws.prepared = pr.p;
+    return 0;
+}
+
+int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, MsmSplit* split) {
+    if (split) { split->parts = 0; split->shift = 0; split->count = 0; split->pts = nullptr; split->ready = nullptr; }
+    const uint32_t n_callers = (uint32_t)pr.p.size();
+    if (n_callers == 0) return 0;
+    MsmLaunchShape L;
+    { int rc = msm_shape(ws, pr, L); if (rc) return rc; }
+    const bool cut = L.cut;
+    uint32_t nmax = L.nmax; const size_t total = L.total, total_nz = L.total_nz;
+    const std::vector<MsmProblem>& launch_p = L.launch_p;
+    const bool uploaded = msm_same_problems(ws.prepared, pr.p);   // msm_prepare_problems, same stream, earlier
+    ws.prepared.clear();
+    if (!uploaded) {
+        if (cut) msm_upload_problems(s, L.parents_p, false, ws.parents);
+        msm_upload_problems(s, launch_p, true, ws.problems);
     }
     const uint32_t count = (uint32_t)launch_p.size();
-    msm_upload_problems(s, launch_p, true, ws.problems);
     ws.final_problems = cut ? ws.parents : ws.problems;
     if (nmax == 0) {
         hipLaunchKernelGGL(msm_final, dim3((4 * count + 63) / 64), dim3(64), 0, s, ws.window_sums, ws.problems, count, MsmPlan{0, 2, 0, 3});
