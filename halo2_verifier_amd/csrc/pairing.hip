@@ -462,6 +462,7 @@ struct alignas(16) PairShared2 {
     uint2 prog[PAIR2_MAX_STEPS];
 };
 static_assert(sizeof(PairShared2) <= 64 * 1024, "k_pairing2's static LDS");
+static_assert(sizeof(PairShared2) + H2V_AUX_LDS_RESERVE > 160 * 1024, "the auxiliary-stream kernels' LDS request must not fit beside a k_pairing2 workgroup (internal.h)");
 __global__ void __launch_bounds__(2 * PAIR_THREADS, 1) k_pairing2(uint32_t n, const PairingConsts* __restrict__ consts, const uint2* __restrict__ prog, uint32_t n_steps,
                                                                const Fq2* __restrict__ pre, uint32_t* __restrict__ ok) {
     __builtin_amdgcn_s_setprio(3);
@@ -653,6 +654,7 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
 // k_pairing's LDS (70 KB: 102 lines, 19 six-form registers, the table) is above the 64 KB a kernel gets without asking; per device, once
 static int pair1_lds_grant() {
     static_assert(sizeof(PairShared1) <= 80 * 1024, "two workgroups of k_pairing per CU");
+    static_assert(sizeof(PairShared1) + H2V_AUX_LDS_RESERVE > 160 * 1024, "the auxiliary-stream kernels' LDS request must not fit beside a k_pairing workgroup");
     H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_pairing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PairShared1)));
     return 0;
 }
