@@ -155,3 +155,19 @@ def test_single_stream_and_fallback_kernels_stay_exact(pool, knobs):
         assert ctx.verify_batch(P_rej, I[:n], rand) == exp_rej
         assert ctx.verify_each(P[:6], I_bad[:6]) == [0, 0, 0, -2, 0, 0]
     ctx.close()
+
+
+@pytest.mark.parametrize("wpw", [2, 4])
+def test_several_windows_per_workgroup_on_small_batches(pool, wpw):
+    """Small batches have narrow windows (16 .. 64 buckets, one lane per bucket): with several windows per workgroup forced, a wave
+    holds lanes of several windows and the window reduction's butterfly runs over 16- or 32-lane segments (csrc/msm.hip: msm_window,
+    both its one-wave form and the form with several waves).  Same accumulators as the oracle."""
+    s, P, I = pool
+    ctx = _ctx(s)
+    rnd = random.Random(31 + wpw)
+    for n in (1, 3, 10, 20, 64):
+        rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+        exp = circuits.oracle_verify_batch(s, P[:n], I[:n], rand)
+        with _tuned(ctx, msm_window_wpw=wpw):
+            assert ctx.verify_batch(P[:n], I[:n], rand) == exp, n
+    ctx.close()
