@@ -210,7 +210,6 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     const uint32_t G = b->groups, gs = n / G;
     b->with_pairing = with_pairing != 0; b->launched = true;
     int rc;
-    H2V_HIP_CHECK(hipMemsetAsync(b->fold_failed, 0, 4 * (size_t)G, s));   // set by h2v_batch_fold_check_enqueue only
     int ev = 0;
     auto mark = [&]() { if (b->profiling >= 2) hipEventRecord(b->ev[ev], s); ++ev; };   // (an event record is a barrier packet: ~6 us of idle stream each)
     mark();
@@ -219,7 +218,11 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     // stage 2: absorbed stream, Blake2b challenges, batch multipliers.  The status words are cleared first, then the auxiliary stream is
     // forked: the scalar canonicity check (proof bytes only) runs there beside the decompression, with the multipliers
     const bool run_decompress = !b->decompressed;
-    if (run_decompress && (rc = decompress_begin_enqueue(s, g))) return rc;
+    // cleared per launch: fold_failed (set by h2v_batch_fold_check_enqueue only) and — unless the upload already did (h2v_batch_upload_launch) —
+    // the status words.  The results block is [ok][fold_failed][out_ident][out_bytes][status]: one fill from fold_failed to the last status word
+    // (the output bytes in between are written later in the launch) instead of two
+    if (run_decompress && n) H2V_HIP_CHECK(hipMemsetAsync(b->fold_failed, 0, (size_t)((uint8_t*)(b->status + n) - (uint8_t*)b->fold_failed), s));
+    else H2V_HIP_CHECK(hipMemsetAsync(b->fold_failed, 0, 4 * (size_t)G, s));
     H2V_HIP_CHECK(hipEventRecord(b->ev_fork0, s));   // everything enqueued before this point (uploads, the cleared status words) is visible to the auxiliary stream
     if (run_decompress && (rc = decompress_range_enqueue(s, g, 0, n))) return rc;
     b->decompressed = false;   // (a later h2v_batch_launch on the same upload runs the stage again: every launch does all of its work)
