@@ -639,7 +639,7 @@ def main():
     ap.add_argument("--no-reupload-leg", action="store_true", help="skip the extra PCIe-inclusive leg (value_reupload)")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the extra 8192-proofs-per-GPU leg (BASELINE.json configs 3/5)")
     ap.add_argument("--config3-steps", type=int, default=8)
-    ap.add_argument("--repeats", type=int, default=11, help="a timed region shorter than 50 ms is run this many times and the median reported (1 = never repeat; SURVEY.md §8(d): at least 10 warm runs, median)")
+    ap.add_argument("--repeats", type=int, default=21, help="a timed region shorter than 50 ms is run this many times and the median reported (1 = never repeat; SURVEY.md §8(d): at least 10 WARM runs, median — the first six or seven runs of a process are a clock ramp, profiles/r03_repeat_curve.txt)")
     ap.add_argument("--tuning", default="", help="measurement aid: forced kernel variants, key=value[,key=value...] of h2v_tuning (default: automatic)")
     ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the config-4 (lookup-heavy VK) and SingleStrategy legs")
     ap.add_argument("--dry-run", action="store_true", help="print the launch plan (and, for N > 1, prove the N-rank rendezvous over gloo) without touching the GPU")
