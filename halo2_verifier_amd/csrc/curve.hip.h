@@ -190,6 +190,50 @@ template <int W> __host__ __device__ inline __attribute__((noinline)) Fq fq_sqrt
 }
 H2V_FN Fq fq_sqrt_candidate(const Fq& a) { return fq_sqrt_candidate_w<4>(a); }
 
+// The same exponentiation as a LOOP over runs of the schedule — "s squarings, then multiply by table entry i" — with ONE inlined squaring
+// and ONE inlined product in its body (device only; k_decompress).  The straight-line form above calls the out-of-line product 312 times
+// and the compiler spends 43 instructions per call site on moving the nine limbs in and out of the argument registers: 13 500 of the
+// ~79 000 instructions of a square root.  Here the value stays in its registers; the table entry is picked by selects (the run table is
+// wave-uniform: scalar loads).
+struct FqSqrtRuns { uint8_t nsq[160]; uint8_t idx[160]; int n; int first; };   // idx 255: no multiplication behind the run's squarings
+template <int W> constexpr FqSqrtRuns fq_sqrt_runs() {
+    constexpr FqSqrtSchedule S = fq_sqrt_schedule<W>();
+    FqSqrtRuns r{};
+    r.n = 0; r.first = -1;
+    int pending = 0;
+    for (int k = 0; k < S.n; ++k) {
+        if (S.op[k] == 0) { if (r.first >= 0) ++pending; continue; }       // squarings of the leading 1 are skipped
+        if (r.first < 0) { r.first = S.op[k] - 1; continue; }              // the first window: r = t[first]
+        r.nsq[r.n] = (uint8_t)pending; r.idx[r.n] = (uint8_t)(S.op[k] - 1); ++r.n; pending = 0;
+    }
+    if (pending) { r.nsq[r.n] = (uint8_t)pending; r.idx[r.n] = 255; ++r.n; }
+    return r;
+}
+#if defined(__HIPCC__)
+__device__ __constant__ const FqSqrtRuns fq_sqrt_runs_w3 = fq_sqrt_runs<3>();
+__device__ __forceinline__ Fq fq_sqrt_candidate_loop_w3(const Fq& a) {
+    Fq t0 = a;
+    const Fq a2 = a.sqr_inl();
+    const Fq t1 = Fq::mul_inl(t0, a2), t2 = Fq::mul_inl(t1, a2), t3 = Fq::mul_inl(t2, a2);   // a, a^3, a^5, a^7
+    auto pick = [&](uint32_t i) -> Fq {
+        Fq s;
+#pragma unroll
+        for (int l = 0; l < H2V_LIMBS; ++l) s.v[l] = i == 0 ? t0.v[l] : (i == 1 ? t1.v[l] : (i == 2 ? t2.v[l] : t3.v[l]));
+        return s;
+    };
+    Fq r = pick((uint32_t)fq_sqrt_runs_w3.first);
+    const int n = fq_sqrt_runs_w3.n;
+#pragma unroll 1
+    for (int k = 0; k < n; ++k) {
+        const uint32_t nsq = fq_sqrt_runs_w3.nsq[k], idx = fq_sqrt_runs_w3.idx[k];
+#pragma unroll 1
+        for (uint32_t i = 0; i < nsq; ++i) r = r.sqr_inl();
+        if (idx != 255u) r = Fq::mul_inl(r, pick(idx));
+    }
+    return r;
+}
+#endif
+
 // G1Affine::from_bytes (compressed).  Returns false for an invalid encoding.
 H2V_FN bool g1_decompress(const uint8_t in[32], G1A& out) {
     uint8_t tmp[32];

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64, 4) k_decompress(const uint8_t* __restrict_
         else {
             const Fq three = {{FqParams::ONE(0), FqParams::ONE(1), FqParams::ONE(2), FqParams::ONE(3), FqParams::ONE(4), FqParams::ONE(5), FqParams::ONE(6), FqParams::ONE(7), FqParams::ONE(8)}};
             const Fq rhs = x.sqr() * x + (three + three + three);
-            Fq y = fq_sqrt_candidate_w<3>(rhs);
+            Fq y = fq_sqrt_candidate_loop_w3(rhs);
             if (y.sqr() != rhs) ok = false;
             else {
                 y.to_raw(yraw);                       // canonical y: its parity decides the sign, its bytes are absorbed
