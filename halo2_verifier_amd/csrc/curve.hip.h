@@ -228,7 +228,11 @@ __device__ __forceinline__ Fq fq_sqrt_candidate_loop_w3(const Fq& a) {
         const uint32_t nsq = fq_sqrt_runs_w3.nsq[k], idx = fq_sqrt_runs_w3.idx[k];
 #pragma unroll 1
         for (uint32_t i = 0; i < nsq; ++i) r = r.sqr_inl();
-        if (idx != 255u) r = Fq::mul_inl(r, pick(idx));
+        // (idx is wave-uniform: four copies of the product behind scalar branches instead of 27 selects in front of one)
+        if (idx == 0u) r = Fq::mul_inl(r, t0);
+        else if (idx == 1u) r = Fq::mul_inl(r, t1);
+        else if (idx == 2u) r = Fq::mul_inl(r, t2);
+        else if (idx == 3u) r = Fq::mul_inl(r, t3);
     }
     return r;
 }
