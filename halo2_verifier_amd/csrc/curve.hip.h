@@ -169,8 +169,8 @@ template <int W> constexpr FqSqrtSchedule fq_sqrt_schedule() {   // sliding wind
     }
     return s;
 }
-// W = 3 (a table of four odd powers: 36 registers instead of 72, ten more products in ~320) is what the decompression kernel
-// uses: at its four waves per SIMD the 4-bit table did not fit the 128-register budget and spilled
+// (Host code and the odd device caller use this straight-line form; k_decompress runs fq_sqrt_candidate_loop_w3 below — W = 3: a table
+// of four odd powers, 36 registers instead of 72, ten more products in ~320; the 4-bit table does not fit four waves per SIMD.)
 template <int W> __host__ __device__ inline __attribute__((noinline)) Fq fq_sqrt_candidate_w(const Fq& a) {
     constexpr FqSqrtSchedule S = fq_sqrt_schedule<W>();
     constexpr int T = 1 << (W - 1);
