@@ -188,7 +188,15 @@ __global__ void __launch_bounds__(256) k_stream_build(const TranscriptSrc* __res
 }
 
 // ------------------------------------------------------------------ BLAKE2b (RFC 7693)
-__device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int c) { return (x >> c) | (x << (64 - c)); }
+// a 64-bit rotation by a constant is two v_alignbit_b32 (the shift / shift / or form the compiler makes of the C expression is four instructions)
+__device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int c) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (c == 32) return ((unsigned long long)lo << 32) | hi;
+    const uint32_t a = c < 32 ? hi : lo, b = c < 32 ? lo : hi;      // rotating by c >= 32 = swapping the halves, then by c - 32
+    const uint32_t k = (uint32_t)(c & 31);
+    const uint32_t nl = __builtin_amdgcn_alignbit(a, b, k), nh = __builtin_amdgcn_alignbit(b, a, k);
+    return ((unsigned long long)nh << 32) | nl;
+}
 __constant__ unsigned long long BLAKE_IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
                                                0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
 __constant__ uint8_t BLAKE_SIGMA[12][16] = {
