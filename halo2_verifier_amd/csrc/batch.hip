@@ -378,10 +378,15 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
         b->last_ms[6] = tacc;
     }
     std::vector<char> all_ok(G, 1);
-    for (uint32_t i = 0; i < n; ++i) {
-        int v = status_decode(st[i]);
+    // (the common case — no proof of the launch was rejected — is found by a word-wide scan: decoding 20 480 statuses one by one, with a
+    // division each for the group, was 30 us of host time behind the GPU's last kernel)
+    uint32_t any = 0;
+    for (uint32_t i = 0; i < n; ++i) any |= (uint32_t)st[i];
+    if (!any) { if (per_proof_status && n) memset(per_proof_status, 0, sizeof(int) * (size_t)n); }
+    else for (uint32_t g = 0, i = 0; g < G; ++g) for (uint32_t k = 0; k < gs; ++k, ++i) {
+        const int v = status_decode(st[i]);
         if (per_proof_status) per_proof_status[i] = v;
-        if (v != 0) all_ok[i / gs] = 0;
+        if (v != 0) all_ok[g] = 0;
     }
     for (uint32_t g = 0; g < G; ++g) {
         // a sharded group is accepted only if no shard reported a failed proof (their terms are zeroed out of the accumulators)
