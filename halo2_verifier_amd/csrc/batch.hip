@@ -228,24 +228,9 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     b->decompressed = false;   // (a later h2v_batch_launch on the same upload runs the stage again: every launch does all of its work)
     mark();
     if ((rc = transcript_stage_enqueue(s, g))) return rc;
-    // the batch multipliers depend only on the uploaded draws: they run on the auxiliary stream beside decompression and transcript
-    if (n) {
-        H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork0, 0));
-        hipStream_t sm = b->aux;
-        if (run_decompress && (rc = decompress_finish_enqueue(sm, g))) return rc;   // k_check_scalars
-        // multipliers: suffix products of the uploaded draws — or, for a batch that is a non-contiguous subset of a larger
-        // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
-        if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(sm, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
-        else if ((rc = multipliers_enqueue(sm, b->tail, b->n_tail, n, G, b->mult))) return rc;
-        // the program writes only the slots the left channel uses; with ONE left term per proof the MSM reads exactly those (a strided problem, below)
-        if (!(pl.left_term_order.size() == 1 && !pl.left_term_order[0].first)) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, sm));
-        H2V_HIP_CHECK(hipEventRecord(b->ev_join0, sm));
-        H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join0, 0));   // joined before the Fr program reads them
-    }
-    mark();
     // both channels of every group in one set of launches: [2g] left (SHPLONK: sum_p m_p * h2_p; GWC: the witness points),
     // [2g+1] right = the group's pooled Guard terms + its folded VK-wide bases.  Both index the same point array; unused
-    // slots have zero scalars and cost nothing.  The descriptors are addresses and sizes: they go to the device in FRONT of the Fr program.
+    // slots have zero scalars and cost nothing.  The descriptors are addresses and sizes: they go to the device on the auxiliary stream, beside the decompression (msm_prepare_problems below).
     MsmProblems pr;
     {
         const uint32_t np = pl.n_points;
@@ -268,7 +253,22 @@ int launch_impl(h2v_batch* b, int with_pairing) {
         }
     }
     b->ws.tune = ctx->tuning;
-    if (n && (rc = msm_prepare_problems(s, b->ws, pr))) return rc;
+    // the batch multipliers depend only on the uploaded draws: they run on the auxiliary stream beside decompression and transcript
+    if (n) {
+        H2V_HIP_CHECK(hipStreamWaitEvent(b->aux, b->ev_fork0, 0));
+        hipStream_t sm = b->aux;
+        if (run_decompress && (rc = decompress_finish_enqueue(sm, g))) return rc;   // k_check_scalars
+        // multipliers: suffix products of the uploaded draws — or, for a batch that is a non-contiguous subset of a larger
+        // accumulation (h2v_verify_batch_shapes), gathered from the multipliers of the whole sequence
+        if (b->ext_mult) { if ((rc = gather_multipliers_enqueue(sm, b->ext_mult, b->ext_idx, n, b->mult))) return rc; }
+        else if ((rc = multipliers_enqueue(sm, b->tail, b->n_tail, n, G, b->mult))) return rc;
+        // the program writes only the slots the left channel uses; with ONE left term per proof the MSM reads exactly those (the strided problem above)
+        if (!(pl.left_term_order.size() == 1 && !pl.left_term_order[0].first)) H2V_HIP_CHECK(hipMemsetAsync(b->left_scal, 0, (size_t)n * pl.n_points * 32, sm));
+        if ((rc = msm_prepare_problems(sm, b->ws, pr))) return rc;   // (5 us of launch + kernel boundary that the main stream's chain no longer carries)
+        H2V_HIP_CHECK(hipEventRecord(b->ev_join0, sm));
+        H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join0, 0));   // joined before the Fr program reads them
+    }
+    mark();
     FrvmArgs a{pd->code, (uint32_t)pl.code.size(), pd->consts, b->slots, n, b->proofs, pl.proof_len, pd->scalar_offsets, b->inst, pl.n_instance_values,
                b->chal, b->mult, b->status, b->msm_scal, pl.n_points, b->shared, b->left_scal, b->insteval, b->guard_scal, (uint32_t)pl.guard_term_order.size()};
     if (n && pl.wide_instances) {

@@ -24,7 +24,7 @@
 //                   directly; the head and tail pieces of a chunk go to a side array and
 //                   the lane where such a bucket begins lists it (empty buckets are recognised by their count downstream);
 //      msm_fixup    a second, dense launch sums the listed buckets' pieces (buckets spread over more than 64 chunks — skewed
-//                   inputs — go to msm_fixup_heavy, one workgroup each)
+//                   inputs — are summed by one wave each, in the same launch)
 //   5. msm_window   sum_b (b+1) * bucket[b] per (problem, window) by per-lane running sums over a slice of buckets, then a cross-lane
 //                   butterfly (wave shuffles) or LDS tree: one wave per window, or two waves (four-wave workgroups of two windows,
 //                   so that every wave has a SIMD to itself), or four for more than 2048 buckets
@@ -83,8 +83,8 @@ static inline uint32_t msm_accumulate_blocks(size_t max_entries, size_t R) {
 #define MSM_FIXUP_SERIAL 64u     // a bucket spread over more chunks than this is summed by a workgroup
 #define MSM_FIXUP_TEAM 3u        // ... over more than this, by a team of eight lanes (the rest: one lane per bucket)
 #define MSM_FIXUP_TEAM_BLOCKS 256u
+#define MSM_FIXUP_HEAVY_BLOCKS 256u  // one-wave workgroups of msm_fixup for the buckets spread over more than MSM_FIXUP_SERIAL chunks
 #define MSM_WIN_THREADS 256
-#define MSM_HEAVY_THREADS 256
 
 // lanes that share a window's bucket reduction: one wave up to 2048 buckets, four beyond.  A window's reduction is a dependent
 // chain of 2 * slice + ~c + log2(T) group additions on every lane (phases of one wave in the 20-step launch, by s_memtime: running
@@ -754,10 +754,36 @@ __device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts,
         if (live && r == 0) bucket_pts[b] = acc;
     }
 }
+// Buckets spread over more than MSM_FIXUP_SERIAL chunks (skewed inputs: one digit value shared by thousands of scalars; none in a launch
+// of ordinary proofs): one wave each, the pieces dealt to its 64 lanes, then a butterfly over the lanes.  (Until round 3 a launch of its
+// own with 256-lane workgroups: 6 us of kernel boundary in every launch for a list that is almost always empty.)
+__device__ __noinline__ void msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
+                                             const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, const MsmSeg& g, uint32_t first_block) {
+    const uint32_t n_heavy = counts[nb], t = threadIdx.x;
+    const uint32_t CH = msm_chunk_len(counts[nb + 1], g.lanes_round);
+    // every wave reaches the exit condition: the heavy list is complete before this kernel starts
+    for (uint32_t h = blockIdx.x - first_block; h < n_heavy; h += MSM_FIXUP_HEAVY_BLOCKS) {
+        const uint32_t b = lists[nb - 1 - h];
+        const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
+        const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
+        G1J acc = G1J::identity();
+        for (uint32_t i = i0 + t; i <= i1; i += 64) acc = g1_add(acc, msm_piece_src(partial, i, i0, off, CH)->p);
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            G1J other;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
+#pragma unroll
+            for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 64);
+            acc = g1_add(acc, other);   // lanes t >= 64 - d add a value they do not own: harmless, only lane 0 is kept
+        }
+        if (t == 0) bucket_pts[b] = acc;
+    }
+}
 __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                                 const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
     if (blockIdx.x < MSM_FIXUP_TEAM_BLOCKS) { msm_fixup_team(counts, offsets, partial, lists, bucket_pts, nb, g); return; }
-    const uint32_t k = (blockIdx.x - MSM_FIXUP_TEAM_BLOCKS) * blockDim.x + threadIdx.x;
+    if (blockIdx.x < MSM_FIXUP_TEAM_BLOCKS + MSM_FIXUP_HEAVY_BLOCKS) { msm_fixup_heavy(counts, offsets, partial, lists, bucket_pts, nb, g, MSM_FIXUP_TEAM_BLOCKS); return; }
+    const uint32_t k = (blockIdx.x - MSM_FIXUP_TEAM_BLOCKS - MSM_FIXUP_HEAVY_BLOCKS) * blockDim.x + threadIdx.x;
     if (k >= counts[nb + 2]) return;
     const uint32_t b = lists[k];
     const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
@@ -770,30 +796,6 @@ __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ cou
     if (!ok) { msm_fixup_slow(partial, i0, i1, off, CH, bucket_pts + b); return; }
     bucket_pts[b] = acc;
 }
-__global__ void __launch_bounds__(MSM_HEAVY_THREADS) msm_fixup_heavy(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
-                                                                     const uint32_t* __restrict__ heavy, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
-    __shared__ G1J red[MSM_HEAVY_THREADS];
-    const uint32_t n_heavy = counts[nb];
-    const uint32_t t = threadIdx.x;
-    // every workgroup reaches the exit condition: the heavy list is complete before this kernel starts
-    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const uint32_t b = heavy[nb - 1 - h];
-        const uint32_t cnt = counts[b], off = msm_bin_start(g, offsets, b);
-        const uint32_t CH = msm_chunk_len(counts[nb + 1], g.lanes_round);
-        const uint32_t i0 = off / CH, i1 = (off + cnt - 1) / CH;
-        G1J acc = G1J::identity();
-        for (uint32_t i = i0 + t; i <= i1; i += MSM_HEAVY_THREADS) acc = g1_add(acc, *msm_piece_src(partial, i, i0, off, CH));
-        red[t] = acc;
-        __syncthreads();
-        for (uint32_t d = MSM_HEAVY_THREADS / 2; d > 0; d >>= 1) {
-            if (t < d) red[t] = g1_add(red[t], red[t + d]);
-            __syncthreads();
-        }
-        if (t == 0) bucket_pts[b] = red[0];
-        __syncthreads();
-    }
-}
-
 #define MSM_WIN_SLOTS 5   // LDS points per lane of msm_window: running sum, weighted sum, scaled (later the tree), 2 run, 3 run
 // The out-of-line group law with explicit destinations: operands are loaded from wherever they live (LDS here), the
 // result is stored where the caller says — no hidden return-value temporaries in scratch memory.
@@ -1081,8 +1083,9 @@ static bool msm_same_problems(const std::vector<MsmProblem>& a, const std::vecto
     return true;
 }
 // The problem descriptors depend on addresses and sizes only: a caller that knows them before the scalars exist (the batch verifier,
-// while the Fr program still runs) hands them to the device early — the same stream, in front of the kernel that produces the scalars —
-// and msm_enqueue_multi finds them there (two 5 us launches and a kernel boundary off the chain behind the Fr program).
+// while the Fr program still runs) hands them to the device early — on the stream of the MSM in front of the kernel that produces the
+// scalars, or on a stream that is joined into it before the MSM (the batch verifier's auxiliary stream, beside the decompression) — and
+// msm_enqueue_multi finds them there (two 5 us launches and a kernel boundary off the chain behind the Fr program).
 int msm_prepare_problems(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr) {
     ws.prepared.clear();
     if (pr.p.empty()) return 0;
@@ -1105,7 +1108,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
     const bool cut = L.cut;
     uint32_t nmax = L.nmax; const size_t total = L.total, total_nz = L.total_nz;
     const std::vector<MsmProblem>& launch_p = L.launch_p;
-    const bool uploaded = msm_same_problems(ws.prepared, pr.p);   // msm_prepare_problems, same stream, earlier
+    const bool uploaded = msm_same_problems(ws.prepared, pr.p);   // msm_prepare_problems, earlier in stream order
     ws.prepared.clear();
     if (!uploaded) {
         if (cut) msm_upload_problems(s, L.parents_p, false, ws.parents);
@@ -1167,8 +1170,7 @@ int msm_enqueue_multi(hipStream_t s, MsmWorkspace& ws, const MsmProblems& pr, Ms
         } else hipLaunchKernelGGL(kern, dim3(acc_blocks), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, phi_tab, ws.redo);
     }
     hipLaunchKernelGGL(msm_accumulate_redo, dim3(256), dim3(64), 0, s, ws.problems, nbq, ws.counts, ws.offsets, ws.list, ws.bucket_pts, ws.partial, nb, g, ws.counts + nb, ws.cursor, ws.redo);
-    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64 + MSM_FIXUP_TEAM_BLOCKS), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
-    hipLaunchKernelGGL(msm_fixup_heavy, dim3(256), dim3(MSM_HEAVY_THREADS), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
+    hipLaunchKernelGGL(msm_fixup, dim3((nb + 63) / 64 + MSM_FIXUP_TEAM_BLOCKS + MSM_FIXUP_HEAVY_BLOCKS), dim3(64), 0, s, ws.counts, ws.offsets, ws.partial, ws.cursor, ws.bucket_pts, nb, g);
     {
         // Two-wave workgroups land on overlapping SIMD pairs when a CU holds two of them (measured: 0.57 ms for what one wave per
         // window does in 0.48), so beyond 256 windows a workgroup is FOUR waves reducing two windows, two waves each: every wave
