@@ -170,10 +170,11 @@ std::vector<uint32_t> pairing_program(bool merged) {
 // can be cut like the MSM's:
 //   Miller loop   f = prod_i L_i^(2^(63 - i)): group A runs iterations 0 .. 21 and then squares its value 42 more times, group B runs
 //                 iterations 22 .. 63 and the two Frobenius corrections, one product joins them: 86 steps instead of 130;
-//   x-powers      a^x = (a^hi)^(2^h) a^lo over the signed-window digits of x: A does the high digits and the h squarings, B the low
-//                 digits; the table of odd powers is built by both (a^4 = (a^2)^2 beside a^3, a^5 = a a^4 beside a^7 = a^3 a^4);
+//   x-powers      a^x = prod over the set bits k of a^(2^k), right to left: A runs the 62 squarings, B multiplies the squares in as they
+//                 appear — 63 steps per x-power (a left-to-right chain pays its multiplications in sequence: 70 with signed windows
+//                 cut between the streams, 75 on one stream);
 //   the tail of the hard part pairs what is independent (y9 | y10, y12 | y11, ...).
-// Both groups step together (two barriers per step); a step's two operations never write, or write and read, the same register.
+// Both groups step together (one barrier per step); a step's two operations never write, or write and read, the same register.
 // One step = uint2 (operation of A, operation of B), 0 = nothing to do.
 #define PAIR2_LOGICAL_REGS 19   // the table below names registers 0 .. 18
 #define PAIR2_REGS 22           // physical registers (pair_rename_registers)
@@ -211,63 +212,36 @@ std::vector<uint32_t> pairing_program2() {
     a1(MUL(R, T1, T0));                    // nu f^(p^6 - 1)
     a1(FROB(T0, R)); a1(FROB(T0, T0));
     a1(MUL(R, T0, R));                     // ^(p^2 + 1)
-    // d = a^BN_X for a in the cyclotomic subgroup, d != a
-    std::vector<int> dig;   // width-4 non-adjacent form of x, least significant first
-    for (unsigned long long n = BN_X; n;) {
-        int z = 0;
-        if (n & 1) { z = (int)(n & 15); if (z >= 8) z -= 16; n -= (unsigned long long)(long long)z; }
-        dig.push_back(z);
-        n >>= 1;
-    }
-    auto tab = [&](int z) { return (uint32_t)(TAB + 2 * ((z < 0 ? -z : z) >> 1) + (z < 0 ? 1 : 0)); };
-    // digits [lo, hi) of x applied to register d by square-and-multiply, `extra` squarings behind them
-    auto chain = [&](std::vector<uint32_t>& col, uint32_t d, size_t lo, size_t hi, size_t extra) {
-        bool started = false;
-        for (size_t i = hi; i-- > lo;) {
-            if (started) col.push_back(SQR(d, d));
-            if (!dig[i]) continue;
-            if (started) col.push_back(MUL(d, d, tab(dig[i]))); else { col.push_back(COPY(d, tab(dig[i]))); started = true; }
-        }
-        for (size_t i = 0; i < extra; ++i) col.push_back(SQR(d, d));
-    };
-    // the cut that makes the longer of the two streams shortest; the low part must not be empty (x is odd: digit 0 is not zero)
-    size_t cut = 1, best = ~(size_t)0;
-    for (size_t h = 1; h + 1 < dig.size(); ++h) {
-        if (!dig[dig.size() - 1]) break;
-        std::vector<uint32_t> ca, cb;
-        chain(ca, 0, h, dig.size(), h); chain(cb, 0, 0, h, 0);
-        const size_t len = std::max(ca.size(), cb.size());
-        if (len < best) { best = len; cut = h; }
-    }
+    // d = a^BN_X, d != a, RIGHT TO LEFT over the bits of x: A squares s <- s^2 (s_k = a^(2^k) in D2), B multiplies d by s_k wherever bit k is
+    // set — one step behind A, in the same steps — so an x-power is as deep as its 62 squarings + 1 (round 3; until then left to right
+    // with signed windows, the digits cut between the streams: 5 steps of table + 64 + 1 to join = 70).  Bit 0 of x is set: d starts as a.
+    int top = 63;
+    while (!((BN_X >> top) & 1ull)) --top;
     auto pow_x = [&](uint32_t d, uint32_t a) {
-        ab(COPY(TAB, a), SQR(D2, a));                        // a                | a^2
-        ab(MUL(TAB + 2, TAB, D2), SQR(d, D2));               // a^3              | a^4   (d is free until its chain starts)
-        ab(MUL(TAB + 4, TAB, d), MUL(TAB + 6, TAB + 2, d));  // a^5 = a a^4      | a^7 = a^3 a^4
-        ab(CONJ(TAB + 1, TAB), CONJ(TAB + 3, TAB + 2));
-        ab(CONJ(TAB + 5, TAB + 4), CONJ(TAB + 7, TAB + 6));
-        sync();
-        chain(A, d, cut, dig.size(), cut);                   // (a^hi)^(2^cut)
-        chain(B, D2, 0, cut, 0);                             // a^lo
-        a1(MUL(d, d, D2));
+        ab(SQR(D2, a), COPY(d, a));
+        for (int k = 1; k <= top; ++k) ab(k < top ? SQR(D2, D2) : 0u, ((BN_X >> k) & 1ull) ? MUL(d, d, D2) : 0u);
     };
-    const uint32_t y0 = T0, y1 = T1, y3 = T2, y4 = T3, y6 = T4, u = T5, v = T6;
-    pow_x(y0, R); a1(CONJ(y0, y0));        // y0 = r^-x
-    a1(SQR(y1, y0));                       // y1 = y0^2
-    a1(SQR(u, y1));                        // y2 = y1^2
-    a1(MUL(y3, u, y1));                    // y3 = y2 y1
-    pow_x(y4, y3); a1(CONJ(y4, y4));       // y4 = y3^-x
+    static_assert(BN_X & 1ull, "pow_x starts from bit 0");
+    // The chain of Fuentes-Castaneda et al. wants y0 = r^-x, y4 = y3^-x, y6 = y5^-x (inverses = conjugates in the cyclotomic subgroup).
+    // With z = r^x: y1 = conj(z^2), y3 = conj(z^6), so y4 = conj(y3^x) = (z^6)^x and conj(y3) = z^6 — the two values the tail uses —
+    // need no conjugation at all; y1's runs in B's column beside a squaring (into a register of its own: A reads z^2 in the same step).
+    const uint32_t y0 = T0, y1 = TAB, z2 = T1, y3 = T2, y4 = T3, y6 = T4, u = T5, v = T6;
+    pow_x(y0, R);                          // z = r^x
+    a1(SQR(z2, y0));                       // z^2
+    ab(SQR(u, z2), CONJ(y1, z2));          // z^4                   | y1 = conj(z^2)
+    a1(MUL(y3, u, z2));                    // z^6 = conj(y3)        (y3 holds the conjugate, which is what the tail multiplies by)
+    pow_x(y4, y3);                         // y4 = y3^-x = (z^6)^x
     a1(SQR(u, y4));                        // y5 = y4^2
-    pow_x(y6, u);                          // (the single-stream table conjugates y6 twice here: y5^-x and back)
-    a1(CONJ(y3, y3));
+    pow_x(y6, u);                          // y5^x = conj(y6)       (likewise)
     a1(MUL(u, y6, y4));                    // y7 = y6 y4
     a1(MUL(u, u, y3));                     // y8 = y7 y3            (u = y8)
     ab(MUL(v, u, y1), MUL(y0, u, y4));     // y9 = y8 y1 (v)        | y10 = y8 y4
-    ab(FROB(y1, v), MUL(y0, y0, R));       // y12 = y9^p            | y11 = y10 r
-    ab(MUL(y0, y1, y0), FROB(u, u));       // y13 = y12 y11         | y8^p
-    ab(CONJ(y1, R), FROB(u, u));           // conj(r)               | y8^(p^2)
-    ab(MUL(y1, y1, v), MUL(y0, u, y0));    // conj(r) y9            | y14 = y8^(p^2) y13
-    a1(FROB(y1, y1)); a1(FROB(y1, y1)); a1(FROB(y1, y1));   // y15
-    a1(MUL(y0, y1, y0));                   // y16
+    ab(FROB(z2, v), MUL(y0, y0, R));       // y12 = y9^p            | y11 = y10 r
+    ab(MUL(y0, z2, y0), FROB(u, u));       // y13 = y12 y11         | y8^p
+    ab(CONJ(z2, R), FROB(u, u));           // conj(r)               | y8^(p^2)
+    ab(MUL(z2, z2, v), MUL(y0, u, y0));    // conj(r) y9            | y14 = y8^(p^2) y13
+    a1(FROB(z2, z2)); a1(FROB(z2, z2)); a1(FROB(z2, z2));   // y15
+    a1(MUL(y0, z2, y0));                   // y16
     a1(pair_op(P_CHECK, 0, y0, 0));
     sync();
     pair_rename_registers({&A, &B}, PAIR2_LOGICAL_REGS, PAIR2_REGS);
