@@ -41,7 +41,7 @@ namespace h2v {
 #define PAIR1_REGS 19        // physical registers of k_pairing (a product writes a fresh one: pair_rename_registers)
 #define PAIR_MAX_OPS 512
 
-enum PairOpCode : uint32_t { P_SQR = 1, P_MUL = 2, P_MULL = 3, P_CONJ = 4, P_FROB = 5, P_CONJ0 = 6, P_COPY = 7, P_CHECK = 8 };
+enum PairOpCode : uint32_t { P_SQR = 1, P_MUL = 2, P_MULL = 3, P_CONJ = 4, P_FROB = 5, P_CONJ0 = 6, P_COPY = 7, P_CHECK = 8, P_FROB2 = 9, P_FROB3 = 10, P_FROB4 = 11 };   // P_FROBn: x^(p^n)
 static inline uint32_t pair_op(uint32_t op, uint32_t d, uint32_t a, uint32_t b) { return op | (d << 8) | (a << 16) | (b << 24); }
 
 // Physical registers.  The kernels run a product in ONE phase — operands read at its start, result written at its end, one barrier per
@@ -62,7 +62,7 @@ static void pair_rename_registers(std::vector<std::vector<uint32_t>*> cols, uint
             uint32_t& x = (*col)[i];
             const uint32_t op = x & 255u, d = (x >> 8) & 255u, a = (x >> 16) & 255u, b = x >> 24;
             if (!op) continue;
-            const bool fresh = (op >= P_SQR && op <= P_MULL) || op == P_FROB;
+            const bool fresh = (op >= P_SQR && op <= P_MULL) || op == P_FROB || op >= P_FROB2;
             const uint32_t pa = map[a], pb = op == P_MUL ? map[b] : b;   // P_MULL: b is a line index
             uint32_t pd2 = op == P_CHECK ? 0u : map[d];
             if (fresh) { pd2 = spare.back(); spare.pop_back(); release.push_back(map[d]); renamed.push_back({d, pd2}); }
@@ -80,7 +80,7 @@ std::vector<uint32_t> pairing_program(bool merged) {
     auto sqr = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_SQR, d, a, 0)); };
     auto mul = [&](uint32_t d, uint32_t a, uint32_t b) { p.push_back(pair_op(P_MUL, d, a, b)); };
     auto conj = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_CONJ, d, a, 0)); };
-    auto frob = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_FROB, d, a, 0)); };
+    auto frob = [&](uint32_t d, uint32_t a, uint32_t n = 1) { p.push_back(pair_op(n == 1 ? P_FROB : (n == 2 ? P_FROB2 : (n == 3 ? P_FROB3 : P_FROB4)), d, a, 0)); };   // ^(p^n)
     auto copy = [&](uint32_t d, uint32_t a) { p.push_back(pair_op(P_COPY, d, a, 0)); };
     // Miller loop: one squaring and one line product per doubling step, one more line product per addition step
     // (merged: the doubling and addition lines of one iteration arrive already multiplied together, k_pair_lines: one line
@@ -96,8 +96,8 @@ std::vector<uint32_t> pairing_program(bool merged) {
     // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
     conj(T1, F);                       // conj(f) = f^(p^6)
     mul(T2, F, T1);                    // N = f conj(f), in Fq6 (even powers of w)
-    frob(T3, T2); frob(T3, T3);        // N^(p^2)
-    frob(T4, T3); frob(T4, T4);        // N^(p^4)
+    frob(T3, T2, 2);                   // N^(p^2)
+    frob(T4, T2, 4);                   // N^(p^4)
     mul(T3, T3, T4);                   // T = N^(p^2) N^(p^4)
     mul(T4, T2, T3);                   // Norm(N) = N T, in Fq2 (coefficient 0)
     // No inversion: 1 / Norm(N) = conj(Norm(N)) / nu with nu = |Norm(N)|^2 in Fq, and the scalar is carried instead of divided out.  From
@@ -109,7 +109,7 @@ std::vector<uint32_t> pairing_program(bool merged) {
     mul(T3, T3, T4);                   // nu N^-1
     mul(T0, T1, T3);                   // nu f^-1
     mul(R, T1, T0);                    // nu f^(p^6 - 1)
-    frob(T0, R); frob(T0, T0);
+    frob(T0, R, 2);
     mul(R, T0, R);                     // ^(p^2 + 1)
     // hard part: the x-power chain of Fuentes-Castaneda et al. (y0 .. y16); inverses in the cyclotomic subgroup are conjugates
     // d = a^BN_X for a in the cyclotomic subgroup (a^-1 = conj(a)), d != a: width-4 signed windows over the exponent — the odd
@@ -154,11 +154,11 @@ std::vector<uint32_t> pairing_program(bool merged) {
     mul(y0, y0, R);                    // y11 = y10 r           (y0 = y11)
     frob(y1, v);                       // y12 = y9^p
     mul(y0, y1, y0);                   // y13 = y12 y11
-    frob(u, u); frob(u, u);            // y8^(p^2)
+    frob(u, u, 2);                     // y8^(p^2)
     mul(y0, u, y0);                    // y14
     conj(y1, R);
     mul(y1, y1, v);                    // conj(r) y9
-    frob(y1, y1); frob(y1, y1); frob(y1, y1);   // y15
+    frob(y1, y1, 3);                   // y15
     mul(y0, y1, y0);                   // y16
     p.push_back(pair_op(P_CHECK, 0, y0, 0));
     pair_rename_registers({&p}, PAIR_REGS, PAIR1_REGS);
@@ -190,6 +190,9 @@ std::vector<uint32_t> pairing_program2() {
     auto MULL = [](uint32_t d, uint32_t a, uint32_t l) { return pair_op(P_MULL, d, a, l); };
     auto CONJ = [](uint32_t d, uint32_t a) { return pair_op(P_CONJ, d, a, 0); };
     auto FROB = [](uint32_t d, uint32_t a) { return pair_op(P_FROB, d, a, 0); };
+    auto FROB2 = [](uint32_t d, uint32_t a) { return pair_op(P_FROB2, d, a, 0); };
+    auto FROB3 = [](uint32_t d, uint32_t a) { return pair_op(P_FROB3, d, a, 0); };
+    auto FROB4 = [](uint32_t d, uint32_t a) { return pair_op(P_FROB4, d, a, 0); };
     auto COPY = [](uint32_t d, uint32_t a) { return pair_op(P_COPY, d, a, 0); };
     // Miller loop over the merged line table (entry i: iteration i; 64, 65: the Frobenius corrections); FA = FB = 1 at the start
     const int K = 22;
@@ -201,25 +204,30 @@ std::vector<uint32_t> pairing_program2() {
     // final exponentiation, easy part: r = f^((p^6 - 1)(p^2 + 1))
     const uint32_t F = FA;
     a1(CONJ(T1, F));                       // conj(f) = f^(p^6)
-    a1(MUL(T2, F, T1));                    // N = f conj(f), in Fq6 (even powers of w)
-    a1(FROB(T3, T2)); a1(FROB(T3, T3));    // N^(p^2)
-    a1(FROB(T4, T3)); a1(FROB(T4, T4));    // N^(p^4)
+    ab(MUL(T2, F, T1), SQR(T5, T1));       // N = f conj(f), in Fq6 (even powers of w)   | conj(f)^2
+    ab(FROB2(T3, T2), FROB4(T4, T2));      // N^(p^2)               | N^(p^4)
     a1(MUL(T3, T3, T4));                   // T = N^(p^2) N^(p^4)
     a1(MUL(T4, T2, T3));                   // Norm(N) = N T, in Fq2 (coefficient 0)
     a1(pair_op(P_CONJ0, T4, T4, 0));       // conj(Norm(N)) = nu / Norm(N), nu in Fq: the scalar is carried, not divided out (pairing_program)
     a1(MUL(T3, T3, T4));                   // nu N^-1
-    a1(MUL(T0, T1, T3));                   // nu f^-1
-    a1(MUL(R, T1, T0));                    // nu f^(p^6 - 1)
-    a1(FROB(T0, R)); a1(FROB(T0, T0));
+    a1(MUL(R, T5, T3));                    // nu f^(p^6 - 1) = conj(f)^2 nu N^-1
+    a1(FROB2(T0, R));
     a1(MUL(R, T0, R));                     // ^(p^2 + 1)
     // d = a^BN_X, d != a, RIGHT TO LEFT over the bits of x: A squares s <- s^2 (s_k = a^(2^k) in D2), B multiplies d by s_k wherever bit k is
     // set — one step behind A, in the same steps — so an x-power is as deep as its 62 squarings + 1 (round 3; until then left to right
     // with signed windows, the digits cut between the streams: 5 steps of table + 64 + 1 to join = 70).  Bit 0 of x is set: d starts as a.
     int top = 63;
     while (!((BN_X >> top) & 1ull)) --top;
-    auto pow_x = [&](uint32_t d, uint32_t a) {
+    // `side`: operations that touch neither a, d nor D2, run in order in B's free steps (the zero bits of x)
+    auto pow_x = [&](uint32_t d, uint32_t a, std::vector<uint32_t> side = {}) {
         ab(SQR(D2, a), COPY(d, a));
-        for (int k = 1; k <= top; ++k) ab(k < top ? SQR(D2, D2) : 0u, ((BN_X >> k) & 1ull) ? MUL(d, d, D2) : 0u);
+        size_t done = 0;
+        for (int k = 1; k <= top; ++k) {
+            uint32_t wb = ((BN_X >> k) & 1ull) ? MUL(d, d, D2) : 0u;
+            if (!wb && done < side.size()) wb = side[done++];
+            ab(k < top ? SQR(D2, D2) : 0u, wb);
+        }
+        for (; done < side.size(); ++done) a1(side[done]);   // (x has zero bits to spare)
     };
     static_assert(BN_X & 1ull, "pow_x starts from bit 0");
     // The chain of Fuentes-Castaneda et al. wants y0 = r^-x, y4 = y3^-x, y6 = y5^-x (inverses = conjugates in the cyclotomic subgroup).
@@ -232,16 +240,14 @@ std::vector<uint32_t> pairing_program2() {
     a1(MUL(y3, u, z2));                    // z^6 = conj(y3)        (y3 holds the conjugate, which is what the tail multiplies by)
     pow_x(y4, y3);                         // y4 = y3^-x = (z^6)^x
     a1(SQR(u, y4));                        // y5 = y4^2
-    pow_x(y6, u);                          // y5^x = conj(y6)       (likewise)
-    a1(MUL(u, y6, y4));                    // y7 = y6 y4
-    a1(MUL(u, u, y3));                     // y8 = y7 y3            (u = y8)
-    ab(MUL(v, u, y1), MUL(y0, u, y4));     // y9 = y8 y1 (v)        | y10 = y8 y4
-    ab(FROB(z2, v), MUL(y0, y0, R));       // y12 = y9^p            | y11 = y10 r
-    ab(MUL(y0, z2, y0), FROB(u, u));       // y13 = y12 y11         | y8^p
-    ab(CONJ(z2, R), FROB(u, u));           // conj(r)               | y8^(p^2)
-    ab(MUL(z2, z2, v), MUL(y0, u, y0));    // conj(r) y9            | y14 = y8^(p^2) y13
-    a1(FROB(z2, z2)); a1(FROB(z2, z2)); a1(FROB(z2, z2));   // y15
-    a1(MUL(y0, z2, y0));                   // y16
+    const uint32_t cr = TAB + 1, yr = TAB + 2, w = TAB + 3, y43 = TAB + 4;
+    pow_x(y6, u, {CONJ(cr, R), MUL(yr, y4, R), MUL(y43, y4, y3)});   // y5^x = conj(y6) (likewise)      | beside it: conj(r), y4 r, y4 y3
+    a1(MUL(u, y6, y43));                   // y8 = y7 y3 = y6 (y4 y3)      (u = y8)
+    ab(MUL(v, u, y1), MUL(y0, u, yr));     // y9 = y8 y1 (v)        | y11 = y8 y4 r
+    ab(FROB(z2, v), MUL(w, cr, v));        // y12 = y9^p            | conj(r) y9
+    ab(MUL(y0, z2, y0), FROB3(w, w));      // y13 = y12 y11         | y15 = (conj(r) y9)^(p^3)
+    ab(MUL(y0, y0, w), FROB2(u, u));       // y13 y15               | y8^(p^2)
+    a1(MUL(y0, y0, u));                    // y16 = y8^(p^2) y13 y15
     a1(pair_op(P_CHECK, 0, y0, 0));
     sync();
     pair_rename_registers({&A, &B}, PAIR2_LOGICAL_REGS, PAIR2_REGS);
@@ -400,12 +406,15 @@ __device__ __forceinline__ void pair_step6(uint32_t op, uint32_t rd, uint32_t ra
 // place: pairing_program2 gives it a fresh destination): lane (k, form, coordinate) for t < 72 — conj(c) gamma^k as two dot2 over stored forms, re = c0 g0 + c1 g1, im = c0 g1 +
 // (-c1) g0, one per lane of a pair; the pair swaps them (as a call to Fq2::mul on every lane this step cost 8700 cycles, a product step 3700).
 __device__ __forceinline__ void pair_coefficients6(uint32_t op, uint32_t rd, uint32_t ra, Coef6 (*reg)[6], const PairingConsts* __restrict__ consts, uint32_t t) {
-    if (op == P_FROB) {
+    if (op == P_FROB || op >= P_FROB2) {
         if (t >= 72) return;
         const uint32_t k = t / 12, which = (t % 12) >> 1, coord = t & 1u;
         const Coef6& x = reg[ra][k];
-        const Fq2 gm = consts->gamma1[k];                        // gamma^0 = 1: (c0, -c1) comes out of the same two dot2
-        const Fq mine = Fq::dot2_inl(x.f[0], coord ? gm.c1 : gm.c0, coord ? x.f[2] : x.f[1], coord ? gm.c0 : gm.c1);
+        // x^(p^n): odd n conjugates the coefficient — conj(c) g: re = c0 g0 + c1 g1, im = c0 g1 + (-c1) g0; even n: c g: re = c0 g0 + (-c1) g1,
+        // im = c0 g1 + c1 g0 (g in Fq then, g1 = 0: the same two dot2 either way)
+        const bool cj = op == P_FROB || op == P_FROB3;
+        const Fq2 gm = (op == P_FROB ? consts->gamma1 : (op == P_FROB2 ? consts->gamma2 : (op == P_FROB3 ? consts->gamma3 : consts->gamma4)))[k];   // gamma^0 = 1
+        const Fq mine = Fq::dot2_inl(x.f[0], coord ? gm.c1 : gm.c0, (coord != 0) == cj ? x.f[2] : x.f[1], coord ? gm.c0 : gm.c1);
         Fq other;
 #pragma unroll
         for (int l = 0; l < 9; ++l) other.v[l] = dpp_u32<0xB1>(mine.v[l]);   // quad_perm [1, 0, 3, 2]: the pair's other coordinate

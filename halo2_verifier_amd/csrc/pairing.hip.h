@@ -73,9 +73,12 @@ struct Fq6 {
     H2V_HD bool operator==(const Fq6& o) const { return c0 == o.c0 && c1 == o.c1 && c2 == o.c2; }
 };
 
-// Frobenius coefficients xi^(i (p-1)/6), i = 1..5, computed once on the host
+// Frobenius coefficients xi^(i (p-1)/6), i = 1..5, computed once on the host: (sum a_k w^k)^p = sum conj(a_k) gamma1[k] w^k.  The higher
+// powers as tables of their own (one step each in the pairing kernels' operation tables): ^(p^2): a_k gamma2[k], gamma2 = gamma1 conj(gamma1)
+// in Fq;  ^(p^3): conj(a_k) gamma3[k], gamma3 = gamma1 gamma2;  ^(p^4): a_k gamma4[k], gamma4 = gamma2^2
 struct PairingConsts {
     Fq2 gamma1[6];
+    Fq2 gamma2[6], gamma3[6], gamma4[6];
     Fq two_inv;
     Fq2 twist_b;  // 3 / xi
 };

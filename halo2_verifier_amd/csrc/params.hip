@@ -33,6 +33,7 @@ PairingConsts pairing_consts_host() {
     }
     k.gamma1[0] = Fq2::one();
     for (int i = 1; i < 6; ++i) k.gamma1[i] = k.gamma1[i - 1] * g;
+    for (int i = 0; i < 6; ++i) { k.gamma2[i] = k.gamma1[i] * k.gamma1[i].conj(); k.gamma3[i] = k.gamma1[i] * k.gamma2[i]; k.gamma4[i] = k.gamma2[i].sqr(); }
     k.two_inv = Fq::from_u32(2).inv();
     Fq2 three = {Fq::from_u32(3), Fq::zero()};
     k.twist_b = three * xi.inv();
