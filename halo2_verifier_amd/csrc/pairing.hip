@@ -546,18 +546,20 @@ __global__ void __launch_bounds__(PAIR_THREADS) k_pairing(const G1J* __restrict_
 #define PL_MAX_EL (2 * PL_MAX_PARTS)   // sparse pairs per iteration: parts x (doubling, addition)
 struct PairIters { uint8_t first[PAIR_ITERS], cnt[PAIR_ITERS]; };   // iteration -> its lines in the context's tables
 struct PairLinesShared {
-    Coef el0[PL_MAX_EL][6];                         // the tree's elements, ping-pong with u.el1
-    Fq2 prod[2][37];                                // partial products of the general products in flight; [36] stays zero (fq12_fold)
+    Coef el0[PL_MAX_EL][6];                         // the tree's elements, ping-pong with u.t.el1
     union {
         struct { Coef ev[2 * PL_MAX_EL][3]; Fq2 sp[PL_MAX_EL][9]; } l;   // line values (w^0, w^1, w^3) and the sparse products A_u * B_v at [3 u + v]
-        Coef el1[PL_MAX_EL][6];
+        struct { Coef el1[PL_MAX_EL][6]; Fq2 prod[2][37]; } t;           // the tree: partial products of the general products in flight; [36] stays zero (fq12_fold)
     } u;
 };
+// (the tree's buffers share the leaves' space: 23.3 KB instead of 28.6, six workgroups per CU instead of five — the 1320 workgroups of a
+// 20-group launch are all resident at once.  Measured: 50 us either way; the kernel is bound by its half-empty waves — 72 lanes per product —
+// sharing SIMDs, not by a second round.)
+static_assert(sizeof(PairLinesShared) * 6 <= 160 * 1024, "six k_pair_lines workgroups per CU");
 __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __restrict__ ready, uint32_t S, const LineCoeff* __restrict__ tab, PairIters its, Fq2* __restrict__ out) {
     __builtin_amdgcn_s_setprio(3);   // a latency chain: its waves win the issue arbitration over the throughput kernels of other launches in flight
     __shared__ PairLinesShared s;
     const uint32_t it = blockIdx.x, chk = blockIdx.y, t = threadIdx.x;
-    if (t < 2) s.prod[t][36] = Fq2::zero();   // read by fq12_fold; the first barrier below comes before any fold
     const uint32_t first = its.first[it], NP = S * its.cnt[it];   // sparse pair q = li * S + j: the lines (both sides) of piece j at line first + li
     // line leaf l = 2 q + side at the point ready[(2 chk + side) S + j] = (X Z, Y, Z^3): a Y + b (X Z) w + c Z^3 w^3.  Lane (l, k, component).
     for (uint32_t idx = t; idx < 2 * NP * 6; idx += PL_THREADS) {
@@ -608,9 +610,10 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
         if (kind == 0) e.c0 = r; else if (kind == 1) e.c1 = r; else e.n1 = r;
     }
     __syncthreads();
-    // binary tree of general products, two per pass
+    // binary tree of general products, two per pass (its buffers take the place of the leaves')
+    if (t < 2) s.u.t.prod[t][36] = Fq2::zero();   // read by fq12_fold; a barrier below comes before any fold
     uint32_t m = NP, cur = 0;
-    auto el = [](uint32_t which) -> Coef (*)[6] { return which ? s.u.el1 : s.el0; };
+    auto el = [](uint32_t which) -> Coef (*)[6] { return which ? s.u.t.el1 : s.el0; };
     while (m > 1) {   // uniform
         const uint32_t np = m >> 1;
         for (uint32_t p0 = 0; p0 < np; p0 += 2) {
@@ -621,10 +624,10 @@ __global__ void __launch_bounds__(PL_THREADS) k_pair_lines(const G1JSlot* __rest
                 const Coef& a = el(cur)[2 * p][i];
                 const Coef& b = el(cur)[2 * p + 1][j];
                 const Fq r = Fq::dot2_inl(a.c0, coord ? b.c1 : b.c0, a.c1, coord ? b.c0 : b.n1);
-                if (coord) s.prod[slot][pr].c1 = r; else s.prod[slot][pr].c0 = r;
+                if (coord) s.u.t.prod[slot][pr].c1 = r; else s.u.t.prod[slot][pr].c0 = r;
             }
             __syncthreads();
-            if (on) fq12_fold(s.prod[slot], el(cur ^ 1)[p], lt);
+            if (on) fq12_fold(s.u.t.prod[slot], el(cur ^ 1)[p], lt);
             __syncthreads();
         }
         if ((m & 1u) && t < 6) el(cur ^ 1)[np][t] = el(cur)[m - 1][t];   // the odd one out moves up as it is
