@@ -113,13 +113,14 @@ struct h2v_batch {
     uint32_t* guard_scal = nullptr;   // [proof][guard term][8] (h2v_guard_msm with GWC)
     bool want_guard = false;          // the next upload takes the guard variant of the plan
     h2v::G1J* acc = nullptr;      // per group: [2g] left, [2g+1] right
-    uint32_t* ok = nullptr;       // [groups]
+    uint32_t* ok = nullptr;       // [groups] — in the pinned host block (results_host): the pairing kernels write their verdicts straight to the host
     uint8_t* out_bytes = nullptr; uint32_t* out_ident = nullptr;
     uint32_t* fold_failed = nullptr;  // [groups] failed proofs reported by the folded shards (h2v_batch_fold_check_enqueue)
     uint8_t* results = nullptr; uint8_t* results_host = nullptr; size_t results_bytes = 0;   // ok / fold_failed / out_ident / out_bytes / status live in `results`
     h2v::MsmWorkspace ws;
     h2v::MsmSplit split;              // how the last launch left its accumulators to the pairing (parts == 0: whole points in acc)
     bool acc_stale = false;           // a launch without a pairing left pieces only: acc / out_bytes are put together on demand (ensure_whole)
+    bool tail_on_aux = false;         // the last launch's whole accumulators, their bytes and the result copy are still the auxiliary stream's business (close_enqueue): join_tail before the main stream touches them
     void* line_ws = nullptr; size_t line_ws_groups = 0;   // k_pair_lines' output, H2V_PAIRING_LINE_WS_BYTES per group
     size_t cap_proof_bytes = 0, cap_inst_bytes = 0, cap_tail = 0, cap_plan_sig = 0;
     uint32_t stream_words = 0;

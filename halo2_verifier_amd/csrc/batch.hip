@@ -43,16 +43,18 @@ int ensure_buffers(h2v_batch* b, PlanDevice* pd) {
     if ((rc = dev_alloc(b->insteval, N * pl.inst_queries.size()))) return rc;
     if ((rc = dev_alloc(b->guard_scal, N * pl.guard_term_order.size() * 8))) return rc;
     if ((rc = dev_alloc(b->acc, 2 * G))) return rc;
-    // everything h2v_batch_finish reads back sits in ONE block, mirrored by one pinned host buffer: a single copy at the end of a
-    // launch (four separate copies into pageable memory were ~0.13 ms of a 20-step launch): [ok G][fold_failed G][out_ident 2 G]
-    // [out_bytes 128 G][status N]
+    // everything h2v_batch_finish reads back sits in ONE block, mirrored by one pinned host buffer: a single copy per launch (four
+    // separate copies into pageable memory were ~0.13 ms of a 20-step launch): [ok G][fold_failed G][out_ident 2 G][out_bytes 128 G][status N]
+    // (the device block keeps the place of `ok`, unused: the offsets of the two blocks agree)
     b->results_bytes = 144 * G + 4 * N;
     if ((rc = dev_alloc(b->results, b->results_bytes))) return rc;
     if (b->results_host) { hipHostFree(b->results_host); b->results_host = nullptr; }
-    H2V_HIP_CHECK(hipHostMalloc((void**)&b->results_host, b->results_bytes ? b->results_bytes : 1, hipHostMallocDefault));
-    b->ok = reinterpret_cast<uint32_t*>(b->results);
-    b->fold_failed = b->ok + G;
-    b->out_ident = b->ok + 2 * G;
+    H2V_HIP_CHECK(hipHostMalloc((void**)&b->results_host, b->results_bytes ? b->results_bytes : 1, hipHostMallocMapped));
+    // the verdicts are the LAST thing a launch produces: the pairing kernel writes them into the host block itself (one word per group over
+    // PCIe) and no copy follows it; everything else in the block is final before the pairing starts and is copied beside it (close_enqueue)
+    { void* dp = nullptr; H2V_HIP_CHECK(hipHostGetDevicePointer(&dp, b->results_host, 0)); b->ok = reinterpret_cast<uint32_t*>(dp); }
+    b->fold_failed = reinterpret_cast<uint32_t*>(b->results) + G;
+    b->out_ident = reinterpret_cast<uint32_t*>(b->results) + 2 * G;
     b->out_bytes = b->results + 16 * G;
     b->status = reinterpret_cast<int*>(b->results + 144 * G);
     if ((rc = b->ws.alloc((uint32_t)(2 * (N * pl.n_points + G * pl.n_shared)), (uint32_t)(2 * G), (uint32_t)((N + G - 1) / G * pl.n_points + pl.n_shared)))) return rc;
@@ -82,6 +84,7 @@ int os_random_scalars(std::vector<uint8_t>& out, size_t n) {
     return 0;
 }
 
+int join_tail(h2v_batch* b);
 // `overlap`: the copies run on the batch's copy stream in chunks and the decompression of every chunk is enqueued on the batch's own
 // stream behind that chunk's event (h2v_batch_upload_launch); otherwise everything is copied on the batch's stream (h2v_batch_upload).
 int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len, const uint8_t* instances_flat, size_t ncols, const size_t* col_lens,
@@ -89,6 +92,7 @@ int upload_impl(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof
     if (!b || (n && !proofs_flat)) { set_last_error("h2v_batch_upload: null argument"); return H2V_ERR_BAD_ARGUMENT; }
     if (n > b->max_proofs) { set_last_error("h2v_batch_upload: n exceeds the batch capacity"); return H2V_ERR_BAD_ARGUMENT; }
     h2v_ctx* ctx = b->ctx;
+    { H2V_HIP_CHECK(hipSetDevice(ctx->device)); int rcj = join_tail(b); if (rcj) return rcj; }
     if (!ctx->vk) { set_last_error("the context was created without a VerifyingKey"); return H2V_ERR_BAD_ARGUMENT; }
     if (ncols != ctx_total_instance_columns(ctx)) { set_last_error("instances do not match the VK's instance column count"); return H2V_ERR_INVALID_INSTANCES; }  // lib.rs:51-55
     std::vector<size_t> lens(col_lens, col_lens + ncols);
@@ -210,6 +214,7 @@ int launch_impl(h2v_batch* b, int with_pairing) {
     const uint32_t G = b->groups, gs = n / G;
     b->with_pairing = with_pairing != 0; b->launched = true;
     int rc;
+    if ((rc = join_tail(b))) return rc;
     int ev = 0;
     auto mark = [&]() { if (b->profiling >= 2) hipEventRecord(b->ev[ev], s); ++ev; };   // (an event record is a barrier packet: ~6 us of idle stream each)
     mark();
@@ -328,10 +333,21 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     // (beside the pairing: kept off the pairing workgroups' CUs by an LDS request, internal.h)
     if (b->split.parts && (rc = msm_combine_enqueue(b->aux, b->ws, b->split, H2V_AUX_LDS_RESERVE))) return rc;   // acc <- the whole points
     if ((rc = point_to_bytes_enqueue(b->aux, b->acc, b->out_bytes, b->out_ident, 2 * G, H2V_AUX_LDS_RESERVE))) return rc;
+    // the result block (all but the verdicts, which the pairing kernel writes to the host itself) goes back on the auxiliary stream too, and the
+    // main stream does NOT wait for it: its last operation is the pairing kernel — the join (a barrier packet) and the copy behind it were
+    // 16 us at the end of every launch.  h2v_batch_finish waits for both streams; anything else that touches the batch first calls join_tail.
+    H2V_HIP_CHECK(hipMemcpyAsync(b->results_host + 4 * (size_t)G, b->results + 4 * (size_t)G, 140 * (size_t)G + 4 * (size_t)b->n, hipMemcpyDeviceToHost, b->aux));
     H2V_HIP_CHECK(hipEventRecord(b->ev_join, b->aux));
+    b->tail_on_aux = true;
     if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.ready, G, b->split.parts, b->split.shift, b->line_ws, b->ok, b->ctx->tuning.pairing_one_stream != 0))) return rc; }
     else if ((rc = pairing_check_enqueue(s, b->ctx->pairing, b->acc, G, b->ok))) return rc;
-    H2V_HIP_CHECK(hipStreamWaitEvent(s, b->ev_join, 0));
+    return 0;
+}
+// the main stream waits for what the last launch left on the auxiliary stream (before anything new reads or overwrites it)
+int join_tail(h2v_batch* b) {
+    if (!b->tail_on_aux) return 0;
+    b->tail_on_aux = false;
+    H2V_HIP_CHECK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     return 0;
 }
 // the whole accumulators (acc) and their affine bytes, if the last launch left pieces only
@@ -345,6 +361,7 @@ int ensure_whole(h2v_batch* b) {
 }
 // the batch's accumulator records (pieces if the launch left pieces)
 int export_batch_records(h2v_batch* b, void* device_dst) {
+    { int rcj = join_tail(b); if (rcj) return rcj; }
     if (b->split.parts) return export_records_enqueue(b->stream, nullptr, b->split.pts, b->split.parts, b->split.shift, b->status, b->n, b->groups, device_dst);
     return export_records_enqueue(b->stream, b->acc, nullptr, 1, 0, b->status, b->n, b->groups, device_dst);
 }
@@ -356,9 +373,17 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
     hipStream_t s = b->stream;
     const uint32_t n = b->n, G = b->groups, gs = n / G;
     { int rcw = ensure_whole(b); if (rcw) return rcw; }
-    const size_t nbytes = 144 * (size_t)G + 4 * (size_t)n;
-    H2V_HIP_CHECK(hipMemcpyAsync(b->results_host, b->results, nbytes, hipMemcpyDeviceToHost, s));
-    hipError_t e = hipStreamSynchronize(s);
+    hipError_t e;
+    if (b->tail_on_aux) {
+        // a launch that ended in its own pairing checks: the block is on its way on the auxiliary stream, the verdicts come from the kernel
+        b->tail_on_aux = false;
+        e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipEventSynchronize(b->ev_join);
+    } else {
+        const size_t nbytes = 144 * (size_t)G + 4 * (size_t)n;
+        H2V_HIP_CHECK(hipMemcpyAsync(b->results_host + 4 * (size_t)G, b->results + 4 * (size_t)G, nbytes - 4 * (size_t)G, hipMemcpyDeviceToHost, s));
+        e = hipStreamSynchronize(s);
+    }
     if (e != hipSuccess) { set_last_error(std::string("h2v_batch_finish: ") + hipGetErrorString(e)); return H2V_ERR_DEVICE; }
     const uint32_t* okv = reinterpret_cast<const uint32_t*>(b->results_host);
     const uint32_t* foldf = okv + G;
@@ -545,6 +570,7 @@ void h2v_batch_destroy(h2v_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->aux) hipStreamSynchronize(b->aux);   // (the tail of the last launch may still be running there)
     if (b->plan) { ctx_put_plan(b->ctx, b->plan); b->plan = nullptr; }
     hipFree(b->proofs); hipFree(b->inst); hipFree(b->tail); hipFree(b->pts); hipFree(b->phi); hipFree(b->ycanon); hipFree(b->results); hipFree(b->words); hipFree(b->chal);
     hipFree(b->mult); hipFree(b->slots); hipFree(b->msm_scal); hipFree(b->shared); hipFree(b->left_scal); hipFree(b->insteval); hipFree(b->guard_scal); hipFree(b->acc);
@@ -581,6 +607,7 @@ int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t
 int h2v_batch_set_groups(h2v_batch* b, size_t groups) {
     if (!b || !groups || groups > MSM_MAX_PROBLEMS / 2 || groups > b->max_proofs) { set_last_error("h2v_batch_set_groups: bad group count"); return H2V_ERR_BAD_ARGUMENT; }
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->aux) hipStreamSynchronize(b->aux);   // (the tail of the last launch may still be running there)
     if (b->plan) { ctx_put_plan(b->ctx, b->plan); b->plan = nullptr; }
     b->groups = (uint32_t)groups; b->launched = false;  // the next upload re-sizes the workspace
     return 0;
@@ -591,7 +618,7 @@ int h2v_batch_finish_groups(h2v_batch* b, int* per_proof_status, int* group_ok, 
 }
 int h2v_batch_accumulators(h2v_batch* b, void** device_ptr, size_t* nbytes) {
     if (!b || !b->acc || !device_ptr) { set_last_error("h2v_batch_accumulators: nothing uploaded"); return H2V_ERR_BAD_ARGUMENT; }
-    if (b->launched) { H2V_HIP_CHECK(hipSetDevice(b->ctx->device)); int rcw = ensure_whole(b); if (rcw) return rcw; }
+    if (b->launched) { H2V_HIP_CHECK(hipSetDevice(b->ctx->device)); int rcw = join_tail(b); if (!rcw) rcw = ensure_whole(b); if (rcw) return rcw; }
     *device_ptr = b->acc;
     if (nbytes) *nbytes = 2 * sizeof(G1J) * b->groups;   // raw points, no failure word: see h2v_batch_export_accumulators
     return 0;
@@ -603,7 +630,7 @@ int h2v_batch_set_stream(h2v_batch* b, void* hip_stream) {
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->owns_stream && b->stream) hipStreamDestroy(b->stream);
     b->stream = (hipStream_t)hip_stream; b->owns_stream = false;
-    return 0;
+    return join_tail(b);   // (the new stream waits for what the last launch left on the auxiliary stream)
 }
 int h2v_batch_export_accumulators(h2v_batch* b, void* device_dst) {
     if (!b || !b->launched || !device_dst) { set_last_error("h2v_batch_export_accumulators: nothing launched"); return H2V_ERR_BAD_ARGUMENT; }
@@ -614,6 +641,7 @@ int h2v_batch_fold_check_enqueue(h2v_batch* b, const void* device_accumulators, 
     if (!b || !b->launched || !device_accumulators || !n_parts) { set_last_error("h2v_batch_fold_check_enqueue: bad argument"); return H2V_ERR_BAD_ARGUMENT; }
     H2V_HIP_CHECK(hipSetDevice(b->ctx->device));
     int rc;
+    if ((rc = join_tail(b))) return rc;
     const uint32_t G = b->groups;
     // the fold keeps the cut of this rank's own launch: records cut the same way add up piece by piece, the pairing takes the pieces
     // (the folded pieces replace the rank's own in the workspace: they were exported before the collective that brought these records)
