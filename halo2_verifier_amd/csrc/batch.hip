@@ -336,7 +336,8 @@ int close_enqueue(h2v_batch* b, bool with_pairing) {
     // the result block (all but the verdicts, which the pairing kernel writes to the host itself) goes back on the auxiliary stream too, and the
     // main stream does NOT wait for it: its last operation is the pairing kernel — the join (a barrier packet) and the copy behind it were
     // 16 us at the end of every launch.  h2v_batch_finish waits for both streams; anything else that touches the batch first calls join_tail.
-    H2V_HIP_CHECK(hipMemcpyAsync(b->results_host + 4 * (size_t)G, b->results + 4 * (size_t)G, 140 * (size_t)G + 4 * (size_t)b->n, hipMemcpyDeviceToHost, b->aux));
+    // (by a kernel, not hipMemcpyAsync: a copy enqueued now, behind kernels that end a launch later, can hold up an SDMA queue — util.hip)
+    if ((rc = copy_words_enqueue(b->aux, b->results + 4 * (size_t)G, b->ok + G, 35 * (size_t)G + (size_t)b->n, H2V_AUX_LDS_RESERVE))) return rc;
     H2V_HIP_CHECK(hipEventRecord(b->ev_join, b->aux));
     b->tail_on_aux = true;
     if (b->split.parts) { if ((rc = pairing_check_split_enqueue(s, b->ctx->pairing, b->split.ready, G, b->split.parts, b->split.shift, b->line_ws, b->ok, b->ctx->tuning.pairing_one_stream != 0))) return rc; }
@@ -378,7 +379,7 @@ int finish_impl(h2v_batch* b, int* per_proof_status, int* group_ok, uint8_t* out
         // a launch that ended in its own pairing checks: the block is on its way on the auxiliary stream, the verdicts come from the kernel
         b->tail_on_aux = false;
         e = hipStreamSynchronize(s);
-        if (e == hipSuccess) e = hipEventSynchronize(b->ev_join);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->aux);   // (not hipEventSynchronize on its last event: that wait goes through the runtime's event thread, and a host that re-uploads per launch lost 40 % to it)
     } else {
         const size_t nbytes = 144 * (size_t)G + 4 * (size_t)n;
         H2V_HIP_CHECK(hipMemcpyAsync(b->results_host + 4 * (size_t)G, b->results + 4 * (size_t)G, nbytes - 4 * (size_t)G, hipMemcpyDeviceToHost, s));

@@ -147,6 +147,7 @@ int bases_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, G1A* d_out, 
 // canonical 32-B scalars -> 8 x 32-bit words (validated < r); flags[i] = 1 when >= r
 int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* d_out, uint32_t* d_flags, uint32_t n);
 // Jacobian -> canonical x|y bytes (+ identity flag word after the 64 bytes: out is 68 B aligned to 4)
+int copy_words_enqueue(hipStream_t s, const void* d_src, void* d_dst, size_t n_words, size_t lds_reserve = 0);   // by a kernel (the destination may be mapped host memory)
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n, size_t lds_reserve = 0);
 // Sharded batches exchange H2V_ACC_RECORD_BYTES records per group: [failed, parts, shift, 0][left pieces][right pieces] (h2v.h).
 // export: d_out[g] <- the group's accumulators — pieces [(2g + side) * parts + j] if d_pieces, else the whole points d_acc[2g], [2g+1] —

@@ -152,6 +152,20 @@ int scalars_from_bytes_enqueue(hipStream_t s, const uint8_t* d_bytes, uint32_t* 
     H2V_HIP_CHECK(hipGetLastError());
     return 0;
 }
+// device words -> (mapped host) words by a kernel.  A hipMemcpyAsync enqueued at launch time, behind kernels that finish milliseconds later,
+// may sit on an SDMA engine's in-order queue with its dependency unmet — and the host -> device copies of the NEXT launches queue up behind
+// it (measured: with several launches in flight, h2v_batch_upload_launch blocked for a whole launch, 13.1 -> 8.1 M proofs/s PCIe-inclusive).
+__global__ void __launch_bounds__(256) k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n_words) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
+}
+int copy_words_enqueue(hipStream_t s, const void* d_src, void* d_dst, size_t n_words, size_t lds_reserve) {
+    if (!n_words) return 0;
+    if (lds_reserve > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_copy_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reserve));
+    hipLaunchKernelGGL(k_copy_words, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), lds_reserve, s, (const uint32_t*)d_src, (uint32_t*)d_dst, (uint32_t)n_words);
+    H2V_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int point_to_bytes_enqueue(hipStream_t s, const G1J* d_in, uint8_t* d_out_xy64, uint32_t* d_is_identity, uint32_t n, size_t lds_reserve) {
     if (!n) return 0;
     if (lds_reserve > 64 * 1024) H2V_HIP_CHECK(hipFuncSetAttribute((const void*)k_point_to_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reserve));

@@ -257,7 +257,10 @@ int h2v_batch_launch(h2v_batch* b, int with_pairing);
 int h2v_batch_upload_launch(h2v_batch* b, size_t n, const uint8_t* proofs_flat, size_t proof_len,
                             const uint8_t* instances_flat, size_t n_instance_columns, const size_t* col_lens,
                             const uint8_t* rand32_tail, size_t n_tail, int with_pairing);
-/* Wait for the stream and fetch results (any pointer may be NULL). */
+/* Wait for the launch and fetch results (any pointer may be NULL).  A launch with its own pairing checks ends on two streams — the
+ * batch's stream (last: the pairing kernel, which writes the verdicts into pinned host memory itself) and an internal auxiliary stream (the
+ * whole accumulators, their bytes, the copy of the result block); this call waits for both.  The batch's stream alone going idle does
+ * NOT mean the results are there; every other h2v_batch_* call orders its work behind that auxiliary stream by itself. */
 int h2v_batch_finish(h2v_batch* b, int* per_proof_status, int* batch_ok, uint8_t out_left_xy[64], uint8_t out_right_xy[64]);
 /* Grouped batches: one upload / launch carries `groups` INDEPENDENT AccumulatorStrategy batches (kzg/strategy.rs:99-141 each):
  * group g owns proofs [g*n/groups, (g+1)*n/groups) and the draws rand32_tail[g*n_tail/groups, (g+1)*n_tail/groups), has its own
