@@ -607,7 +607,7 @@ __device__ __noinline__ void msm_chunk_slow(const MsmProblem* __restrict__ prs, 
             *msm_piece_dst(bucket_pts, partial, lane, b, bin_lo, bin_hi, chunk_lo, chunk_hi, first) = acc;
             acc = G1J::identity(); first = false;
             if (pos == bin_hi && pos < chunk_hi) {
-                do { ++b; } while (counts[b] == 0);
+                { uint32_t tries = 0; do { ++b; } while (counts[b] == 0 && ++tries < 2); if (counts[b] == 0) b = msm_bin_of(g, offsets, pos); }   // (as in msm_accumulate_chunk)
                 bin_lo = bin_hi; bin_hi = bin_lo + counts[b];
                 q = prs[b / nbq];
             }
