@@ -745,7 +745,9 @@ __device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts,
         const uint32_t i0 = off / CH, i1 = cnt ? (off + cnt - 1) / CH : i0;
         // (round 3, same box: taking a lane's first piece as it is instead of adding it to the identity made the kernel 84.5 us instead of
         // 77 — the complete addition returns early on an identity operand, the extra select did not pay; raising the teams' issue
-        // priority over the lane path's waves changed nothing)
+        // priority over the lane path's waves changed nothing; at the end of the round the in-register fast addition was inlined here — one site
+        // in a loop over a lane's own pieces and the three tree levels — in place of the calls: 198 us instead of 77, not kept;
+        // 512 team blocks instead of 256 and two waves per SIMD for the kernel (248 registers): 79 us, no change)
         G1J acc = G1J::identity();
         if (live) for (uint32_t i = i0 + r; i <= i1; i += 8) acc = g1_add(acc, msm_piece_src(partial, i, i0, off, CH)->p);
         for (uint32_t d = 4; d > 0; d >>= 1) {
