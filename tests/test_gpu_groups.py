@@ -177,3 +177,63 @@ def test_groups_gwc_keccak():
         assert circuits.oracle_verify_batch(s, P[sl], I[sl], rand[sl]) == ref
     ctx.close()
     s.free()
+
+
+def test_results_of_a_launch_whose_tail_runs_on_the_auxiliary_stream(pool):
+    """A launch with its own pairing ends on two streams (the pairing kernel writes the verdicts into pinned host memory; the accumulator
+    bytes and statuses come back on the auxiliary stream, not joined into the batch's stream): finish must wait for both, a second finish
+    must return the same, and calls made BEFORE finish — another launch, an upload + launch of different proofs, an export — must order
+    themselves behind that tail."""
+    import torch
+    import halo2_verifier_amd as h2v
+    from halo2_verifier_amd.distributed import ACC_BYTES
+    s, P, I = pool
+    ctx = _ctx(s)
+    G, gs = 4, 16
+    n = G * gs
+    rnd = random.Random(77)
+    rand = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    rand2 = [rnd.randrange(1, R_MOD) for _ in range(n)]
+    want = _grouped(ctx, P[:n], I[:n], rand, G)
+    # the second set of proofs: group 1 holds a proof whose instances do not match
+    P2, I2 = P[n:2 * n], [list(map(list, i)) for i in I[n:2 * n]]
+    I2[gs + 3][0][0] = (5).to_bytes(32, "little")
+    want2 = _grouped(ctx, P2, I2, rand2, G)
+    assert want[0] == [True] * G and want2[0] == [True, False, True, True]
+
+    b = h2v.Batch(ctx, n, 8, groups=G)
+    flat, inst = _flat(P[:n], I[:n])
+    flat2, inst2 = _flat(P2, I2)
+    b.upload(flat, 1024, inst, [8], _rand_bytes(rand))
+    b.launch(True)
+    assert b.finish_groups() == want
+    assert b.finish_groups() == want                     # nothing new enqueued: the same block again
+    b.launch(True); b.launch(True)                       # a launch on top of an unfinished one
+    assert b.finish_groups() == want
+    b.launch(True)
+    rec = torch.zeros(G * ACC_BYTES, dtype=torch.uint8, device="cuda:0")
+    b.export_accumulators(rec.data_ptr())                # reads the whole accumulators the auxiliary stream puts together
+    got = b.finish_groups()
+    assert got == want
+    whole = h2v.Batch(ctx, n, 8, groups=G)
+    whole.upload(flat, 1024, inst, [8], _rand_bytes(rand))
+    whole.launch(False)
+    rec2 = torch.zeros_like(rec)
+    whole.export_accumulators(rec2.data_ptr())
+    whole.finish_groups()
+    # (a launch without a pairing exports its pieces, one with a pairing has put the whole points together: the folded check must agree)
+    for r_ in (rec, rec2):
+        chk = h2v.Batch(ctx, n, 8, groups=G)
+        chk.upload(flat, 1024, inst, [8], _rand_bytes(rand))
+        chk.launch(False)
+        chk.fold_check_enqueue(r_.data_ptr(), 1)
+        okf, _, leftf, rightf = chk.finish_groups()
+        assert (okf, leftf, rightf) == (want[0], want[2], want[3])
+        chk.close()
+    b.launch(True)
+    b.upload(flat2, 1024, inst2, [8], _rand_bytes(rand2))   # new inputs while the previous launch's tail may still run
+    b.launch(True)
+    assert b.finish_groups() == want2
+    b.upload_launch(flat, 1024, inst, [8], _rand_bytes(rand))
+    assert b.finish_groups() == want
+    b.close(); whole.close()
