@@ -732,8 +732,9 @@ __device__ __noinline__ void msm_fixup_slow(const G1JSlot* __restrict__ partial,
 // (Round 3 tried the teams as a kernel of their own — with their calls inside, msm_fixup is compiled for 280 + 32 registers where the
 // lane path alone needs 113: the lane kernel then takes 48 us instead of sharing 77, but the team kernel is a 70 us chain of its own
 // and the two run one after the other: 118 us.  Inside one launch the lane path hides under the teams' chain.)
+__device__ __noinline__ void g1_add_to(G1J* dst, const G1J* a, const G1J* b);   // (defined with msm_window below)
 __device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
-                                            const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, const MsmSeg& g) {
+                                            const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, const MsmSeg& g, G1J* team_acc) {
     const uint32_t n_team = counts[nb + 3], r = threadIdx.x & 7u;
     const uint32_t CH = msm_chunk_len(counts[nb + 1], g.lanes_round);
     // whole waves loop together (the shuffles below need all eight lanes of a team): the trip count is rounded up per wave
@@ -748,17 +749,16 @@ __device__ __noinline__ void msm_fixup_team(const uint32_t* __restrict__ counts,
         // priority over the lane path's waves changed nothing; at the end of the round the in-register fast addition was inlined here — one site
         // in a loop over a lane's own pieces and the three tree levels — in place of the calls: 198 us instead of 77, not kept;
         // 512 team blocks instead of 256 and two waves per SIMD for the kernel (248 registers): 79 us, no change)
-        G1J acc = G1J::identity();
-        if (live) for (uint32_t i = i0 + r; i <= i1; i += 8) acc = g1_add(acc, msm_piece_src(partial, i, i0, off, CH)->p);
-        for (uint32_t d = 4; d > 0; d >>= 1) {
-            G1J other;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
-#pragma unroll
-            for (uint32_t k = 0; k < sizeof(G1J) / 4; ++k) dst[k] = (uint32_t)__shfl_down((int)src[k], d, 8);
-            acc = g1_add(acc, other);   // lanes r >= 8 - d add a neighbour's value they do not own: harmless, only r = 0 is kept
-        }
-        if (live && r == 0) bucket_pts[b] = acc;
+        // The accumulators live in LDS and the additions are the out-of-line routine with explicit operands and destination (as in
+        // msm_window): by value through g1_add, operands and result travelled through scratch memory, ~17 us per addition — a 70 us chain.
+        // A tree level reads the neighbour's slot directly: a wave runs in lockstep, every lane has loaded its operands (first statement of
+        // g1_add_to) before any lane stores its result.
+        G1J* mine = team_acc + threadIdx.x;
+        *mine = G1J::identity();
+        if (live) for (uint32_t i = i0 + r; i <= i1; i += 8) g1_add_to(mine, mine, &msm_piece_src(partial, i, i0, off, CH)->p);
+        for (uint32_t d = 4; d > 0; d >>= 1)
+            g1_add_to(mine, mine, team_acc + min(threadIdx.x + d, 63u));   // lanes r >= 8 - d add a value they do not own: harmless, only r = 0 is kept
+        if (live && r == 0) bucket_pts[b] = *mine;
     }
 }
 // Buckets spread over more than MSM_FIXUP_SERIAL chunks (skewed inputs: one digit value shared by thousands of scalars; none in a launch
@@ -788,7 +788,8 @@ __device__ __noinline__ void msm_fixup_heavy(const uint32_t* __restrict__ counts
 }
 __global__ void __launch_bounds__(64) msm_fixup(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const G1JSlot* __restrict__ partial,
                                                 const uint32_t* __restrict__ lists, G1JSlot* __restrict__ bucket_pts, uint32_t nb, MsmSeg g) {
-    if (blockIdx.x < MSM_FIXUP_TEAM_BLOCKS) { msm_fixup_team(counts, offsets, partial, lists, bucket_pts, nb, g); return; }
+    __shared__ G1J team_acc[64];   // the teams' accumulators (7 KB; the lane path keeps its own in registers)
+    if (blockIdx.x < MSM_FIXUP_TEAM_BLOCKS) { msm_fixup_team(counts, offsets, partial, lists, bucket_pts, nb, g, team_acc); return; }
     if (blockIdx.x < MSM_FIXUP_TEAM_BLOCKS + MSM_FIXUP_HEAVY_BLOCKS) { msm_fixup_heavy(counts, offsets, partial, lists, bucket_pts, nb, g, MSM_FIXUP_TEAM_BLOCKS); return; }
     const uint32_t k = (blockIdx.x - MSM_FIXUP_TEAM_BLOCKS - MSM_FIXUP_HEAVY_BLOCKS) * blockDim.x + threadIdx.x;
     if (k >= counts[nb + 2]) return;
